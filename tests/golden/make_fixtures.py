@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden from the read-only reference checkout.
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    python tests/golden/make_fixtures.py
+
+What it writes
+  scenes/<name>.nff.gz   input data: the reference's own .nff scene files, gzip'd
+  hide.ppm.gz            the one golden image the reference holds (its glass.nff render)
+  golden.json            known answers: sha256 of hide.ppm, and -- per scene -- the image
+                         checksum prefix and ray counts recorded from a run of the reference
+                         itself (see KNOWN below), which the oracle must reproduce.
+"""
+import gzip
+import hashlib
+import json
+import os
+import sys
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SCENES = ["tetra-3", "teapot-3", "balls", "refract", "glass", "glass2", "glass3", "glass4",
+          "ball", "ball2", "2d", "teapot-1", "teapot-2", "tetra-5"]
+
+# Outputs of the reference binary itself (g++ -O3 build of the unmodified sources, 1 spp,
+# aperture 0), recorded when the reference was surveyed: first 12 hex digits of the sha256 of
+# the PPM it wrote, octree node count, closest-hit ray count (Camera.h:318 calls) and
+# shadow-ray count (Camera.h:404 calls).
+KNOWN = {
+    "tetra-3": {"res": [512, 512], "sha12": "7a7a8157c8de", "solids": 64, "nodes": 25,
+                "closest": 324998, "shadow": 67241},
+    "teapot-3": {"res": [512, 512], "sha12": "9e44023cb52b", "sha12_phong": "3cd68de17a4c",
+                 "solids": 570, "nodes": 84, "closest": 488788, "shadow": 460088},
+    "balls": {"res": [512, 512], "sha12": "3c3a2648c47d", "solids": 7383, "nodes": 15485,
+              "closest": 658207, "shadow": 1343448},
+    "refract": {"res": [512, 512], "sha12": "c1a1938aa661", "solids": 570, "nodes": 84,
+                "closest": 867363, "shadow": 1119840},
+    "glass": {"res": [900, 900], "sha12": "21080df183f5", "solids": 8, "nodes": 5,
+              "closest": 2327925, "shadow": 3342978},
+}
+
+
+def gz_write(path, data):
+    # mtime=0 keeps the archive bytes reproducible
+    with open(path, "wb") as raw:
+        with gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0, compresslevel=9) as f:
+            f.write(data)
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference checkout not present; fixtures are committed, nothing to do")
+    os.makedirs(os.path.join(HERE, "scenes"), exist_ok=True)
+    for name in SCENES:
+        with open(os.path.join(REF, name + ".nff"), "rb") as f:
+            data = f.read()
+        gz_write(os.path.join(HERE, "scenes", name + ".nff.gz"), data)
+    with open(os.path.join(REF, "hide.ppm"), "rb") as f:
+        ppm = f.read()
+    gz_write(os.path.join(HERE, "hide.ppm.gz"), ppm)
+    golden = {"hide_ppm_sha256": hashlib.sha256(ppm).hexdigest(), "hide_ppm_scene": "glass",
+              "reference_runs": KNOWN}
+    with open(os.path.join(HERE, "golden.json"), "w") as f:
+        json.dump(golden, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print("wrote", len(SCENES), "scenes, hide.ppm.gz, golden.json")
+
+
+if __name__ == "__main__":
+    main()
