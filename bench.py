@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X render path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A step is one frame: every rank renders its round-robin row bands of the frame through the
+C ABI (scene already resident in HBM), the 8-bit framebuffer is gathered to rank 0 over RCCL
+(N > 1) and re-ordered into the frame.  Rays = closest-hit rays + shadow rays, counted on
+the device.  Rank 0 prints one JSON line.
+
+Workloads (BASELINE.json `configs`):
+    teapot3_8k16  teapot-3.nff geometry at 7680x4320, -s 4 (16 spp)   [default; the config the
+                  1/2/4/8-GPU metric is quoted on; strong scaling over row bands]
+    teapot3       teapot-3.nff at its own 512x512, 1 spp
+    balls         balls.nff 512x512, 1 spp
+    refract       refract.nff 512x512, 1 spp
+    glass         glass.nff 900x900, 1 spp (light-camera term off)
+
+For N > 1 launch as: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    #  name: (scene, resx, resy, N, default steps, default warmup)
+    "teapot3_8k16": ("teapot-3", 7680, 4320, 4, 3, 1),
+    "teapot3": ("teapot-3", 0, 0, 1, 50, 5),
+    "balls": ("balls", 0, 0, 1, 50, 5),
+    "refract": ("refract", 0, 0, 1, 50, 5),
+    "glass": ("glass", 0, 0, 1, 20, 3),
+}
+HBM_PEAK_GBPS = 8000.0
+BAND_ROWS = 16
+
+# Algorithmic bytes per ray (fixed by the reference's traversal, not by what this build fetches):
+#   node tests x 64 B node record + triangle tests x 96 B + sphere tests x 32 B + 192 B of queue
+#   traffic (a 96-byte ray or hit record written once and read once).
+NODE_B, TRI_B, SPH_B, QUEUE_B = 64, 96, 32, 192
+
+
+def cpu_reference_sample(scene_name, threads):
+    """Times the CPU oracle on the scene's own frame (1 spp) and returns rates and per-ray test counts."""
+    import raytracer_amd as rt
+    from oracle import binding as ob
+    o = ob.OracleScene(rt.scene_path(scene_name))
+    out = {}
+    for label, th in (("all", threads), ("two", 2)):
+        t0 = time.perf_counter()
+        fr = o.render(threads=th, flags=ob.FLAG_NO_LIGHTCAM, want_hits=False, want_mask=False)
+        dt = time.perf_counter() - t0
+        c = fr["counters"]
+        out[label] = {"seconds": dt, "threads": th, "mrays_s": (c["closest_rays"] + c["shadow_rays"]) / dt / 1e6}
+    c = fr["counters"]
+    tri_share = o.n_triangles / max(o.n_solids, 1)
+    out["per_ray"] = {
+        "closest_nodes": c["node_tests_closest"] / max(c["closest_rays"], 1),
+        "closest_prims": c["prim_tests_closest"] / max(c["closest_rays"], 1),
+        "shadow_nodes": c["node_tests_shadow"] / max(c["shadow_rays"], 1),
+        "shadow_prims": c["prim_tests_shadow"] / max(c["shadow_rays"], 1),
+    }
+    # scenes here are (almost) purely triangles or purely spheres; price a primitive test by the majority type
+    prim_b = TRI_B if tri_share >= 0.5 else SPH_B
+    out["bytes_per_ray"] = {
+        "closest": out["per_ray"]["closest_nodes"] * NODE_B + out["per_ray"]["closest_prims"] * prim_b + QUEUE_B,
+        "shadow": out["per_ray"]["shadow_nodes"] * NODE_B + out["per_ray"]["shadow_prims"] * prim_b + QUEUE_B,
+    }
+    out["sample"] = "%s.nff %dx%d 1 spp full frame" % (scene_name, o.resx, o.resy)
+    o.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="teapot3_8k16", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="extra RT_FLAG_* bits for the render calls")
+    args = ap.parse_args()
+
+    import torch
+    import raytracer_amd as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus %d needs the torch.distributed.run launcher (see the module docstring)" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene_name, resx, resy, N, dsteps, dwarm = WORKLOADS[args.workload]
+    steps = args.steps if args.steps is not None else dsteps
+    warmup = args.warmup if args.warmup is not None else dwarm
+
+    scene = rt.Scene.load(scene_name)
+    cam = scene.camera(resx, resy)
+    resx, resy = cam.resx, cam.resy
+    gpu = rt.Renderer(local_rank)
+    gpu.upload(scene)
+
+    band = BAND_ROWS if world > 1 else 0
+    rows = rt.part_rows(cam, band, world, rank)
+    max_rows = max(rt.part_rows(cam, band, world, r) for r in range(world))
+    dev = torch.device("cuda", local_rank)
+    local = torch.zeros((max_rows, resx, 3), dtype=torch.uint8, device=dev)
+    frame = gathered = row_index = None
+    if world > 1 and rank == 0:
+        frame = torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev)
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        row_index = [torch.from_numpy(rt.part_row_indices(resy, band, world, r)).to(dev) for r in range(world)]
+
+    def step(flags):
+        st = gpu.render_device(cam, rgb_u8_ptr=local.data_ptr(), num_samples=N, flags=flags, band_rows=band,
+                               n_parts=world, part=rank)
+        if world > 1:
+            dist.gather(local, gathered if rank == 0 else None, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    frame.index_copy_(0, row_index[r], gathered[r][: row_index[r].numel()])
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step(args.flags)
+    fence()
+    t0 = time.perf_counter()
+    rays = 0
+    for _ in range(steps):
+        st = step(args.flags)
+        rays += st["closest_rays"] + st["shadow_rays"]
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # per-kernel times: a few extra frames with HIP events around every launch on the render stream
+    prof_steps = max(1, min(steps, 5))
+    kt = {"closest_ms": 0.0, "shadow_ms": 0.0, "closest_launches": 0, "shadow_launches": 0, "closest_rays": 0,
+          "shadow_rays": 0, "gpu_ms": 0.0}
+    for _ in range(prof_steps):
+        st = step(args.flags | rt.FLAG_TIMING)
+        for k in kt:
+            kt[k] += st[k]
+    fence()
+
+    if world > 1:
+        t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        rays = float(t[1])
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            cpu = cpu_reference_sample(scene_name, threads)
+        roofline = None
+        if cpu is not None:
+            bpr = cpu["bytes_per_ray"]
+            dom = "closest" if kt["closest_ms"] >= kt["shadow_ms"] else "shadow"
+            kname = "k_closest" if dom == "closest" else "k_shadow"
+            launches = max(kt[dom + "_launches"], 1)
+            bytes_total = kt[dom + "_rays"] * bpr[dom]
+            ms_total = kt[dom + "_ms"]
+            achieved = bytes_total / (ms_total * 1e-3) / 1e9 if ms_total > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                        "avg_launch_ms": ms_total / launches, "launches": launches,
+                        "algorithmic_bytes_per_ray": bpr[dom], "rays_per_launch": kt[dom + "_rays"] / launches,
+                        "kernel_ms_per_frame": {"k_closest": kt["closest_ms"] / prof_steps,
+                                                "k_shadow": kt["shadow_ms"] / prof_steps,
+                                                "frame_gpu_ms": kt["gpu_ms"] / prof_steps}}
+        line = {
+            "metric": "Mrays/sec (primary+secondary)",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "scene": scene_name + ".nff", "resolution": [resx, resy],
+                       "spp": N * N, "rays_per_frame": rays / steps,
+                       "partition": "%d-row bands round-robin over %d GPU(s), RCCL gather of RGB8" % (band or resy, world)},
+        }
+        if roofline is not None:
+            line["roofline"] = roofline
+        if cpu is not None:
+            line["cpu_baseline"] = {"value": cpu["all"]["mrays_s"], "unit": "Mrays/s", "cores": cpu["all"]["threads"],
+                                    "kind": "port", "sample": cpu["sample"],
+                                    "two_thread_value": cpu["two"]["mrays_s"],
+                                    "seconds": cpu["all"]["seconds"] + cpu["two"]["seconds"]}
+        print(json.dumps(line), flush=True)
+
+    gpu.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

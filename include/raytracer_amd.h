@@ -1,0 +1,199 @@
+/*
+ * raytracer_amd.h -- C ABI of the MI355X render path.
+ *
+ * The reference (MasonSchuckman/Raytracer) has no plugin or FFI interface; the
+ * boundary this library replaces is the internal C++ call
+ *     renderMultithreaded(Camera)                    Driver.cpp:355-390
+ * i.e. the two-thread loop
+ *     pixels[(i*resx+j)*3+c] = camera.castRay(i,j,root,solids,lights)[c] * 255
+ *                                                    Driver.cpp:735-769, Camera.h:112
+ * with its inputs (the Camera fields of Camera.h:19-46, the globals `root`,
+ * `solids`, `lights`, `resx`, `resy` of Driver.cpp:38-46) passed as plain arrays.
+ *
+ * Two groups of entry points:
+ *   rth_*  host front end: .nff dialect -> triangulated primitives -> octree ->
+ *          flattened arrays (replaces parseInput Driver.cpp:426-691 and
+ *          setupOctree Driver.cpp:224-250 for callers that do not already hold
+ *          the scene in memory).
+ *   rt_*   device path: upload, render, read back.
+ *
+ * All structs are plain C, all sizes in elements unless named *_bytes.  Every
+ * function returns RT_OK (0) or a negative error code; rt_last_error() gives the
+ * message of the calling thread's last failure.  A context is bound to one GPU
+ * and is used from one host thread at a time.
+ */
+#ifndef RAYTRACER_AMD_H
+#define RAYTRACER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* bad argument or inconsistent scene arrays */
+    RT_ERR_DEVICE = -2,       /* HIP runtime error, or no MI355X-class device */
+    RT_ERR_IO = -3,           /* file could not be opened / parsed */
+    RT_ERR_CAPACITY = -4,     /* a ray queue overflowed (never expected; see rt_render) */
+    RT_ERR_UNSUPPORTED = -5
+};
+
+/* Material of the last `f` line (ObjProps, Solid.h:27-36). */
+typedef struct rt_material {
+    double r, g, b, Kd, Ks, Shine, T, ior;
+} rt_material;                                   /* 64 bytes */
+
+/* Light (Light.h:6-20); intensity = 1/sqrt(#lights) (Driver.cpp:685-688). */
+typedef struct rt_light {
+    double pos[3];
+    double color[3];
+    double intensity;
+    double _pad;
+} rt_light;                                      /* 64 bytes */
+
+/* One octree node (Octree<Solid*>, Octree.h:733-907) in depth-first pre-order,
+ * children in the reference's order 0..7.  `skip` is the pre-order index of the
+ * first node that is NOT in this node's subtree, so a traversal needs no stack:
+ * descend = index+1, prune = skip.  The node's resident primitives are two slot
+ * ranges, one into the triangle records and one into the sphere records. */
+typedef struct rt_node {
+    double center[3];          /* bounding-sphere centre = cube centre (Octree.h:791-793) */
+    double radius;             /* size*sqrt(3)/2 (Octree.h:796) */
+    int32_t skip;
+    int32_t tri_begin, tri_count;
+    int32_t sph_begin, sph_count;
+    int32_t depth;
+    int32_t _pad[2];
+} rt_node;                                       /* 64 bytes, one cache line on the host */
+
+/* Triangle record: the per-ray operands of Triangle::intersect (Triangle.h:91-158):
+ * v0 and the precomputed edges ab = v0-v1, ac = v0-v2 (Triangle.h:40-46). */
+typedef struct rt_tri_rec {
+    double v0[3], ab[3], ac[3];
+    int32_t prim;              /* primitive id = index in parse/triangulation order */
+    int32_t _pad0;
+    double _pad1[2];
+} rt_tri_rec;                                    /* 96 bytes */
+
+/* Sphere record: operands of Sphere::intersect (Sphere.h:35-77). */
+typedef struct rt_sph_rec {
+    double center[3];
+    double radius;
+} rt_sph_rec;                                    /* 32 bytes */
+
+#define RT_PRIM_SPHERE 1u          /* else triangle */
+#define RT_PRIM_HAS_VNORMALS 2u    /* triangle came from a `pp` patch (Triangle.h:13) */
+#define RT_SPH_TRANSPARENT 0x80000000u   /* flag bit in sph_prim[]: material T > 0 */
+
+/* Flattened scene.  Arrays are caller-owned host memory, copied by rt_upload_scene. */
+typedef struct rt_scene_desc {
+    const rt_node *nodes;        int32_t n_nodes;
+    const rt_tri_rec *tri;       int32_t n_tri_slots;
+    const rt_sph_rec *sph;       int32_t n_sph_slots;
+    const uint32_t *sph_prim;    /* per sphere slot: primitive id | RT_SPH_TRANSPARENT */
+    int32_t n_prims;
+    const uint32_t *prim_flags;  /* per primitive: RT_PRIM_* */
+    const int32_t *prim_material;/* per primitive: index into materials */
+    const double *prim_normals;  /* per primitive 12 doubles: flat normal, then vertex normals
+                                    n0,n1,n2 (zero unless RT_PRIM_HAS_VNORMALS); spheres: zero */
+    const rt_material *materials; int32_t n_materials;
+    const rt_light *lights;      int32_t n_lights;
+    double background[3];
+    int32_t lightcam_samples;    /* `Z` directive, default 150 (Driver.cpp:41,505-508) */
+    int32_t _pad;
+} rt_scene_desc;
+
+/* Camera after computeCoordinateSystem (Camera.h:64-97). */
+typedef struct rt_camera {
+    double u[3], v[3], w[3], e[3];
+    double d, l, t, pix_width;
+    int32_t resx, resy;
+} rt_camera;
+
+#define RT_FLAG_PHONG_NORMALS 1u   /* `-p`: interpolate patch normals (Triangle.h:144-146) */
+#define RT_FLAG_NO_CULL       2u   /* visit exactly the nodes the reference visits */
+#define RT_FLAG_KEEP_ZERO_WEIGHT 4u/* trace reflection rays whose weight is exactly 0, as the
+                                      reference does (Camera.h:305-306); they change no pixel */
+#define RT_FLAG_TIMING        8u   /* record per-kernel-class HIP-event times into rt_stats */
+
+typedef struct rt_render_opts {
+    int32_t num_samples;       /* N of `-s N`; samples per pixel = N*N (Camera.h:123-125) */
+    double aperture;           /* `-a A`; depth of field when > 0 (Camera.h:114) */
+    uint32_t flags;            /* RT_FLAG_* */
+    uint32_t seed;             /* jitter / lens sampling seed (used when N>1 or aperture>0) */
+    /* Row partition for multi-GPU: rows are cut into bands of `band_rows` rows, band b belongs
+     * to part (b % n_parts).  This call renders the rows of `part`.  n_parts=1 renders all. */
+    int32_t band_rows, n_parts, part;
+    int32_t _pad;
+} rt_render_opts;
+
+/* Output buffers hold only the rows of this part, in ascending row order
+ * (rt_part_rows tells how many).  Any pointer may be NULL. */
+typedef struct rt_frame_out {
+    void *rgb_f64;             /* rows*resx*3 doubles: clamp(colour,0,1)*255 (Driver.cpp:758-760) */
+    void *rgb_u8;              /* rows*resx*3 bytes: (int) truncation (Driver.cpp:722) */
+    void *hit_id;              /* rows*resx int32: primitive hit by the first sample's primary ray, -1 = none */
+    void *lightcam_mask;       /* rows*resx bytes: 1 where a shading point was shadowed only by transparent
+                                  spheres (the light-camera branch, Camera.h:406-451) */
+    int32_t on_device;         /* 1: pointers are device memory of the context's GPU; 0: host memory */
+    int32_t _pad;
+} rt_frame_out;
+
+typedef struct rt_stats {
+    uint64_t closest_rays;     /* calls equivalent to Camera::castRay(ray), Camera.h:318 */
+    uint64_t shadow_rays;      /* calls equivalent to checkOccluded3 from Camera.h:404 */
+    uint64_t lightcam_rays;    /* light-camera rays (LightCam.h:491), reported separately */
+    uint64_t rays_per_generation[6];
+    uint64_t hits_per_generation[6];
+    double gpu_ms;             /* whole frame, HIP events on the context's stream */
+    double closest_ms, shadow_ms, other_ms;   /* only with RT_FLAG_TIMING */
+    uint64_t closest_launches, shadow_launches;
+    int32_t batches;
+    int32_t queue_overflow;
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+typedef struct rth_scene rth_scene;
+
+/* ---- device path ---- */
+const char *rt_last_error(void);
+int rt_device_count(int *count);
+int rt_create(int device_id, rt_ctx **out);
+int rt_destroy(rt_ctx *ctx);
+int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *scene);
+int rt_part_rows(const rt_camera *cam, const rt_render_opts *opts, int32_t *rows);
+/* Renders one frame (replaces renderMultithreaded, Driver.cpp:355-390, minus writeImage).
+ * Synchronous: returns after the outputs are complete. */
+int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *opts, const rt_frame_out *out, rt_stats *stats);
+/* Same, but only enqueues the work on the context's stream; outputs must be device memory.
+ * rt_sync waits and fills `stats`. */
+int rt_render_async(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *opts, const rt_frame_out *out);
+int rt_sync(rt_ctx *ctx, rt_stats *stats);
+/* Primary batch size (primary samples per pipeline pass); 0 restores the default. */
+int rt_set_batch(rt_ctx *ctx, int64_t primaries);
+
+/* ---- host front end ---- */
+/* Parses an .nff file (dialect of Driver.cpp:426-691), ear-clips polygons and patches
+ * (Polygon.h:107-205, PolygonalPatch.h:78-157), builds and flattens the octree. */
+int rth_scene_load(const char *nff_path, rth_scene **out);
+int rth_scene_free(rth_scene *s);
+int rth_scene_desc(const rth_scene *s, rt_scene_desc *out);           /* pointers stay owned by `s` */
+/* Camera for the scene's viewpoint; resx/resy <= 0 take the file's `resolution`. */
+int rth_scene_camera(const rth_scene *s, int32_t resx, int32_t resy, rt_camera *out);
+int rth_scene_resolution(const rth_scene *s, int32_t *resx, int32_t *resy);
+/* Triangle vertices (9 doubles) or sphere centre+radius (4 doubles) of primitive `prim`. */
+int rth_scene_prim_geometry(const rth_scene *s, int32_t prim, double *out9);
+/* writeImage (Driver.cpp:712-733): binary P6 from value*255 doubles, (int) truncation. */
+int rth_write_ppm_f64(const char *path, const double *rgb_f64, int32_t resx, int32_t resy);
+int rth_write_ppm_u8(const char *path, const uint8_t *rgb_u8, int32_t resx, int32_t resy);
+/* Argument scanner with the reference's behaviour (Driver.cpp:167-216, 771-783). */
+int rth_parse_args(int argc, const char *const *argv, int32_t *num_samples, double *aperture, int32_t *phong,
+                   char *input_path, size_t input_cap, char *output_path, size_t output_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACER_AMD_H */

@@ -1,0 +1,89 @@
+"""Builds the native pieces in-tree with hipcc / gcc.
+
+    python -m raytracer_amd.build            # product library + CLI driver + oracle
+    python -m raytracer_amd.build --force    # ignore timestamps
+
+Outputs (git-ignored, shipped to the GPU box with the tree):
+    raytracer_amd/libraytracer_amd.so   HIP kernels + C ABI + host front end (gfx950)
+    raytracer_amd/bin/rt_driver         command-line host
+    oracle/librt_oracle.so, oracle/rt_oracle   CPU checker (tests and cpu_baseline only)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libraytracer_amd.so")
+DRIVER = os.path.join(PKG, "bin", "rt_driver")
+
+# No FMA contraction, no fast-math: the kernels evaluate the reference's FP64 expressions
+# operation for operation.
+DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
+                "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+HOST_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-value"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; the HIP library cannot be built")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build_library(force=False):
+    hipcc = _hipcc()
+    dev_src = os.path.join(CSRC, "rt_device.hip")
+    host_src = os.path.join(CSRC, "host_scene.cpp")
+    header = os.path.join(ROOT, "include", "raytracer_amd.h")
+    deps = [dev_src, host_src, header, os.path.join(CSRC, "host_scene.hpp"), os.path.abspath(__file__)]
+    dev_obj = os.path.join(CSRC, "rt_device.o")
+    host_obj = os.path.join(CSRC, "host_scene.o")
+    if force or _newer(dev_obj, [dev_src, header, os.path.abspath(__file__)]):
+        _run([hipcc] + DEVICE_FLAGS + ["-c", dev_src, "-o", dev_obj])
+    if force or _newer(host_obj, [host_src, header, os.path.join(CSRC, "host_scene.hpp"), os.path.abspath(__file__)]):
+        _run(["g++"] + HOST_FLAGS + ["-c", host_src, "-o", host_obj])
+    if force or _newer(LIB, deps + [dev_obj, host_obj]):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, dev_obj, host_obj])
+    return LIB
+
+
+def build_driver(force=False):
+    src = os.path.join(CSRC, "rt_driver.cpp")
+    os.makedirs(os.path.dirname(DRIVER), exist_ok=True)
+    if force or _newer(DRIVER, [src, LIB]):
+        _run(["g++", "-O2", "-std=c++17", src, "-o", DRIVER, "-L" + PKG, "-lraytracer_amd",
+              "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + "/opt/rocm/lib"])
+    return DRIVER
+
+
+def build_oracle(force=False):
+    odir = os.path.join(ROOT, "oracle")
+    if force:
+        _run(["make", "-C", odir, "clean"])
+    _run(["make", "-C", odir])
+    return os.path.join(odir, "librt_oracle.so")
+
+
+def build_all(force=False):
+    build_library(force)
+    build_driver(force)
+    build_oracle(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,1040 @@
+// MI355X (gfx950) render path: wavefront pipeline of HIP kernels behind the C ABI
+// declared in include/raytracer_amd.h.
+//
+// Pipeline per batch of primary samples (one pass = one ray generation):
+//   k_closest<PRIMARY>  ray generation (Camera.h:112-230) fused with closest-hit traversal
+//                       (Octree.h:996-1062, Triangle.h:91-158, Sphere.h:35-77, 155-204),
+//                       hit record (Solid.h:110-125) and secondary-ray spawning
+//                       (Camera.h:232-314); pushes hit records and next-generation rays
+//                       with one wave-aggregated atomic per queue.
+//   k_shadow            one work item per (hit, light): shadow traversal
+//                       (Octree.h:1198-1264), Phong terms (Solid.h:128-172,
+//                       Camera.h:365-488), f64 atomic accumulation into the frame.
+//   k_closest<QUEUE>    the same traversal for generations 1..5, rays read from the queue.
+//   k_finalize          /spp, clamp, *255, (int) truncation (Camera.h:217-227, Driver.cpp:722,758-760).
+//
+// The octree arrives flattened in depth-first pre-order with skip links, so the
+// traversal carries no stack: "descend" is index+1 and "prune" is node.skip; the
+// visit order is exactly the reference's recursion order (children 0..7).
+//
+// Arithmetic is FP64 in the reference's evaluation order; this file is compiled with
+// -ffp-contract=off so that every +,-,*,/ and sqrt is the same IEEE operation the CPU
+// performs.  Only pow() (specular term) and the order in which a pixel's contributions
+// are summed can differ from a CPU evaluation.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/raytracer_amd.h"
+
+// ------------------------------------------------------------------ errors
+namespace {
+thread_local std::string g_error;
+int fail(int code, const std::string &msg)
+{
+    g_error = msg;
+    return code;
+}
+}  // namespace
+
+extern "C" void rt_set_error_string(const char *msg) { g_error = msg ? msg : ""; }
+extern "C" const char *rt_last_error(void) { return g_error.c_str(); }
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+// ------------------------------------------------------------------ device structs
+struct alignas(16) RayRec {      // 80 bytes
+    double o[3];
+    double d[3];
+    double A;                    // product of T along the chain of refraction calls
+    double coef;                 // coefOfReflection carried by the call (Camera.h:241,305)
+    uint32_t pixel;              // local pixel index
+    uint32_t meta;               // bits 0..7: remaining loop iterations, bit 8: first ray of a call
+    uint32_t _pad[2];
+};
+
+struct alignas(16) HitRec {      // 96 bytes
+    double P[3];                 // impactPos
+    double n[3];                 // hr.normal (normalised once)
+    double e[3];                 // ray origin (hr.e)
+    double weight;               // factor applied to the local colour
+    uint32_t pixel;
+    int32_t prim;                // the solid that was hit (never occludes itself)
+    uint32_t _pad[2];
+};
+
+struct DevScene {
+    const rt_node *nodes;
+    const rt_tri_rec *tri;
+    const rt_sph_rec *sph;
+    const uint32_t *sph_prim;
+    const uint32_t *prim_flags;
+    const int32_t *prim_material;
+    const double *prim_normals;
+    const rt_material *materials;
+    const rt_light *lights;
+    int32_t n_nodes, n_lights;
+    double bg[3];
+};
+
+struct FrameParams {
+    DevScene S;
+    rt_camera cam;
+    int32_t N;                   // samples per axis
+    double aperture;
+    uint32_t flags, seed;
+    int32_t band_rows, n_parts, part, local_rows;
+    int32_t tiles_x;             // 8x8 sub-sample tiles per row of tiles
+    int32_t cull_closest, cull_shadow, exact_shadow_order;
+    double *accum;               // local_rows*resx*3
+    int32_t *hit_id;             // local_rows*resx or null
+    uint8_t *lc_mask;            // local_rows*resx or null
+};
+
+struct QueueSet {
+    RayRec *rays_in;
+    RayRec *rays_out;
+    HitRec *hits;
+    uint32_t *counts;            // [0..6] ray counts per generation, [8..13] hit counts per generation, [15] overflow
+    uint32_t ray_capacity, hit_capacity;
+    int32_t generation;
+    int64_t tile_begin, tile_end;  // PRIMARY only
+};
+
+// ------------------------------------------------------------------ device math
+#define DEV __device__ __forceinline__
+
+struct d3 { double x, y, z; };
+DEV d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV d3 ld3(const double *p) { return mk3(p[0], p[1], p[2]); }
+DEV d3 sub3(d3 a, d3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV d3 add3(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV d3 neg3(d3 a) { return mk3(-a.x, -a.y, -a.z); }
+DEV d3 scale3(double s, d3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+DEV d3 div3(d3 a, double s) { return mk3(a.x / s, a.y / s, a.z / s); }
+DEV double dot3(d3 a, d3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+DEV d3 unit3(d3 a)
+{
+    double z = dot3(a, a);
+    if (z > 0) { double s = sqrt(z); return div3(a, s); }
+    return a;
+}
+DEV double norm3(d3 a) { return sqrt(dot3(a, a)); }
+
+// det of the matrix with columns a, b, c in the reference's association (Triangle.h:388-393)
+DEV double det3(d3 a, d3 b, d3 c)
+{
+    return a.x * (b.y * c.z - c.y * b.z) + b.x * (c.y * a.z - a.y * c.z) + c.x * (a.y * b.z - b.y * a.z);
+}
+
+// Bounding-sphere test of a node (Sphere.h:155-204).  Returns the value the reference
+// returns (t2, t1 or `sentinel`).  The reference takes sqrt(B*B-4AC) without halving it, so
+// its roots are wider than the sphere's; *entry receives the true distance at which the
+// ray enters the sphere, (-b - root/2)/A, which is what pruning may compare against.
+DEV double bound_test(const rt_node *nd, d3 o, d3 d, double A, double minT, double sentinel, double *entry)
+{
+    d3 emp = sub3(o, ld3(nd->center));
+    double r = nd->radius;
+    double C = dot3(emp, emp) - r * r;
+    double B = 2.0 * dot3(d, emp);
+    double disc = B * B - 4 * A * C;
+    *entry = sentinel;
+    if (disc < 0) return sentinel;
+    double b = B / 2;
+    double root = sqrt(disc);
+    double t1 = (-b + root) / A;
+    double t2 = (-b - root) / A;
+    *entry = (-b - 0.5 * root) / A;
+    if (t2 > minT) return t2;
+    else if (t1 > minT) return t1;
+    return sentinel;
+}
+
+// Triangle::intersect (Triangle.h:91-158) without the hit-record update; returns t or maxT.
+DEV double tri_test(const rt_tri_rec *tr, d3 o, d3 d, double minT, double maxT, double *alpha_out, double *beta_out)
+{
+    d3 v0 = ld3(tr->v0), ab = ld3(tr->ab), ac = ld3(tr->ac);
+    d3 ae = sub3(v0, o);
+    double detA = det3(ab, ac, d);
+    double alpha = det3(ae, ac, d) / detA;
+    if (alpha < 0 || alpha > 1) return maxT;
+    double beta = det3(ab, ae, d) / detA;
+    if (beta < 0 || beta > 1 - alpha) return maxT;
+    double t = det3(ab, ac, ae) / detA;
+    if (t < minT || t > maxT) return maxT;
+    *alpha_out = alpha;
+    *beta_out = beta;
+    return t;
+}
+
+// Sphere::intersect (Sphere.h:35-77) without the hit-record update; returns t or maxT.
+DEV double sph_test(const rt_sph_rec *sp, d3 o, d3 d, double d2, double minT, double maxT)
+{
+    d3 emc = sub3(o, ld3(sp->center));
+    double r = sp->radius;
+    double ddotemc = dot3(d, emc);
+    double disc = (ddotemc * ddotemc) - d2 * (dot3(emc, emc) - r * r);
+    if (disc < 0) return maxT;
+    double sq = sqrt(disc);
+    double root1 = (-ddotemc + sq) / d2;
+    double root2 = (-ddotemc - sq) / d2;
+    double t = root1;
+    if (root1 < 0 || (root2 > minT && root2 < root1)) t = root2;
+    if (t < minT || t > maxT) return maxT;
+    return t;
+}
+
+#define SLOT_SPHERE 0x40000000
+
+// Closest hit over the flattened octree (Octree.h:996-1062).  `best` is a triangle slot,
+// a sphere slot | SLOT_SPHERE, or -1.  With `cull`, a node whose bounding sphere is entered
+// beyond the current best hit is pruned; the nearest hit is unchanged by that.
+DEV void trace_closest(const DevScene &S, d3 o, d3 d, bool cull, double &best_t, int &best)
+{
+    const double minT = .01, maxT = 10000000000.0;
+    const double A = dot3(d, d);
+    best_t = maxT;
+    best = -1;
+    int idx = 0;
+    const int end = S.n_nodes;
+    int tcur = 0, tend = 0, scur = 0, send = 0;
+    while (true) {
+        // find the next node with resident primitives
+        while (tcur >= tend && scur >= send && idx < end) {
+            const rt_node *nd = &S.nodes[idx];
+            double entry;
+            double ret = bound_test(nd, o, d, A, minT, maxT, &entry);
+            bool pass = !(ret >= maxT);
+            if (pass && cull && entry > best_t * (1.0 + 1e-12) + 1e-12) pass = false;
+            if (pass) {
+                tcur = nd->tri_begin; tend = tcur + nd->tri_count;
+                scur = nd->sph_begin; send = scur + nd->sph_count;
+                idx = idx + 1;
+            } else {
+                idx = nd->skip;
+            }
+        }
+        if (tcur >= tend && scur >= send) break;
+        while (tcur < tend) {
+            double al, be;
+            double t = tri_test(&S.tri[tcur], o, d, minT, maxT, &al, &be);
+            if (t < best_t) { best_t = t; best = tcur; }
+            ++tcur;
+        }
+        while (scur < send) {
+            double t = sph_test(&S.sph[scur], o, d, A, minT, maxT);
+            if (t < best_t) { best_t = t; best = scur | SLOT_SPHERE; }
+            ++scur;
+        }
+    }
+}
+
+// checkOccluded3 (Octree.h:1198-1264) over the flattened octree.
+// Returns occluded; *only_transparent and *closest as the reference leaves them.
+// The reference returns from a subtree as soon as that subtree's own node saw any
+// occluder, skipping every later sibling; in pre-order that is "shrink the end of the
+// walk to this node's skip link".
+DEV bool trace_shadow(const DevScene &S, d3 o, d3 d, int parent, double maxT, bool cull, bool *only_transparent,
+                      int *closest)
+{
+    const double minT = .01, sentinel = 10000000.0;
+    const double A = dot3(d, d);
+    bool seen = false;
+    *only_transparent = true;
+    *closest = -1;
+    int idx = 0;
+    int end = S.n_nodes;
+    while (idx < end) {
+        const rt_node *nd = &S.nodes[idx];
+        double entry;
+        double ret = bound_test(nd, o, d, A, minT, sentinel, &entry);
+        bool pass = !(ret >= sentinel);
+        if (pass && cull && entry > maxT * (1.0 + 1e-12) + 1e-12) pass = false;
+        if (!pass) { idx = nd->skip; continue; }
+        bool anything = false;
+        double furthest = minT;
+        const int tb = nd->tri_begin, te = tb + nd->tri_count;
+        for (int s = tb; s < te; ++s) {
+            const rt_tri_rec *tr = &S.tri[s];
+            if (tr->prim == parent) continue;
+            double al, be;
+            double t = tri_test(tr, o, d, minT, maxT, &al, &be);
+            if (t < maxT) {   // a triangle always ends the query (Octree.h:1241-1251)
+                if (t > furthest) *closest = tr->prim;
+                *only_transparent = false;
+                return true;
+            }
+        }
+        const int sb = nd->sph_begin, se = sb + nd->sph_count;
+        for (int s = sb; s < se; ++s) {
+            uint32_t tag = S.sph_prim[s];
+            int prim = (int)(tag & ~RT_SPH_TRANSPARENT);
+            if (prim == parent) continue;
+            double t = sph_test(&S.sph[s], o, d, A, minT, maxT);
+            if (t < maxT) {
+                anything = true;
+                if (t > furthest) { furthest = t; *closest = prim; }
+                if (!(tag & RT_SPH_TRANSPARENT)) { *only_transparent = false; return true; }
+            }
+        }
+        if (anything) { seen = true; end = nd->skip; }
+        idx = idx + 1;
+    }
+    return seen;
+}
+
+// Counter-based stand-in for the reference's shared rand() % 1000 / 1000 (Camera.h:99-103).
+DEV uint32_t hash_rng(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
+{
+    uint32_t h = seed * 0x9E3779B1u + 0x85EBCA6Bu;
+    h ^= pixel + 0x9E3779B9u + (h << 6) + (h >> 2);
+    h ^= sample + 0x9E3779B9u + (h << 6) + (h >> 2);
+    h ^= dim + 0x9E3779B9u + (h << 6) + (h >> 2);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+DEV double normed_rand(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
+{
+    return (double)(hash_rng(pixel, sample, dim, seed) % 1000u) / 1000.0;
+}
+
+DEV int global_row(const FrameParams &P, int local_row)
+{
+    int band = local_row / P.band_rows;
+    int within = local_row - band * P.band_rows;
+    return (band * P.n_parts + P.part) * P.band_rows + within;
+}
+
+// Wave-aggregated queue push: one atomic per wave, lanes take consecutive slots.
+DEV uint32_t wave_reserve(bool want, uint32_t *counter, uint32_t capacity, uint32_t *overflow, bool *ok)
+{
+    unsigned long long mask = __ballot(want);
+    uint32_t n = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    if (n) {
+        int leader = __ffsll((long long)mask) - 1;
+        int lane = (int)(threadIdx.x & 63);
+        if (lane == leader) base = atomicAdd(counter, n);
+        base = (uint32_t)__shfl((int)base, leader);
+    }
+    uint32_t rank = (uint32_t)__popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
+    uint32_t slot = base + rank;
+    *ok = want && slot < capacity;
+    if (want && slot >= capacity) *overflow = 1u;
+    return slot;
+}
+
+DEV void accum_add(double *accum, uint32_t pixel, double w, d3 c)
+{
+    unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 0], w * c.x);
+    unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 1], w * c.y);
+    unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 2], w * c.z);
+}
+
+// ------------------------------------------------------------------ kernels
+template <bool PRIMARY>
+__global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const uint32_t in_count = PRIMARY ? 0u : min(Q.counts[Q.generation], Q.ray_capacity);
+    const long long n_chunks = PRIMARY ? (Q.tile_end - Q.tile_begin) : (((long long)in_count + 63) >> 6);
+    const bool cull = P.cull_closest != 0;
+
+    for (long long chunk = wave; chunk < n_chunks; chunk += n_waves) {
+        bool active;
+        d3 o, d;
+        double A = 1.0, coef = 1.0;
+        uint32_t pixel = 0, meta = 5u | 0x100u;
+        bool first_sample = false;
+        if (PRIMARY) {
+            // 8x8 tile of the sub-sample grid (resx*N wide, local_rows*N high)
+            const long long tile = Q.tile_begin + chunk;
+            const int ty = (int)(tile / P.tiles_x), tx = (int)(tile - (long long)ty * P.tiles_x);
+            const int sx = tx * 8 + (lane & 7), sy = ty * 8 + (lane >> 3);
+            const int N = P.N;
+            active = sx < P.cam.resx * N && sy < P.local_rows * N;
+            const int j = sx / N, sj = sx - j * N;
+            const int lrow = sy / N, si = sy - lrow * N;
+            const int i = global_row(P, lrow);
+            pixel = (uint32_t)lrow * (uint32_t)P.cam.resx + (uint32_t)j;
+            first_sample = (si == 0 && sj == 0);
+            const rt_camera &c = P.cam;
+            const uint32_t gpix = (uint32_t)i * (uint32_t)c.resx + (uint32_t)j;
+            const uint32_t sample = (uint32_t)(si * N + sj);
+            double p, q, r;
+            if (N > 1) {
+                double spw = c.pix_width / N;
+                double randX = normed_rand(gpix, sample, 0, P.seed);
+                double randY = normed_rand(gpix, sample, 1, P.seed);
+                randX -= .5;
+                randY -= .5;
+                double edgeX = (j - .5) * c.pix_width;
+                double edgeY = (i - .5) * c.pix_width;
+                double j_m = edgeX + sj * spw + .5 * spw;
+                double i_m = edgeY + si * spw + .5 * spw;
+                randX *= spw;
+                randY *= spw;
+                j_m += randX;
+                i_m += randY;
+                p = c.l + j_m;
+                q = c.t - i_m;
+            } else {
+                p = c.l + j * c.pix_width;
+                q = c.t - i * c.pix_width;
+            }
+            r = -c.d;
+            d3 u = ld3(c.u), v = ld3(c.v), w = ld3(c.w), e = ld3(c.e);
+            d = unit3(add3(add3(scale3(p, u), scale3(q, v)), scale3(r, w)));
+            o = e;
+            if (P.aperture > 0) {
+                d3 uOff = scale3(P.aperture, scale3(normed_rand(gpix, sample, 2, P.seed) - .5, u));
+                d3 vOff = scale3(P.aperture, scale3(normed_rand(gpix, sample, 3, P.seed) - .5, v));
+                o = add3(o, add3(uOff, vOff));
+                p = c.l + j * c.pix_width;
+                q = c.t - i * c.pix_width;
+                d3 focus = add3(add3(add3(scale3(p, u), scale3(q, v)), scale3(r, w)), e);
+                d = unit3(sub3(focus, o));
+            }
+        } else {
+            const long long idx = chunk * 64 + lane;
+            active = idx < (long long)in_count;
+            const RayRec *rr = &Q.rays_in[active ? idx : 0];
+            o = ld3(rr->o);
+            d = ld3(rr->d);
+            A = rr->A;
+            coef = rr->coef;
+            pixel = rr->pixel;
+            meta = rr->meta;
+        }
+
+        if (PRIMARY) {   // generation-0 ray count (queued generations are counted by their pushes)
+            const unsigned long long am = __ballot(active);
+            if (lane == 0 && am) atomicAdd(&Q.counts[0], (uint32_t)__popcll(am));
+        }
+        double best_t = 0;
+        int best = -1;
+        if (active) trace_closest(P.S, o, d, cull, best_t, best);
+
+        const bool first = (meta & 0x100u) != 0;
+        const int L = (int)(meta & 0xffu);
+        const double wloc = first ? A : A * coef;
+        bool hit = active && best >= 0;
+        if (active && !hit) accum_add(P.accum, pixel, wloc, ld3(P.S.bg));
+
+        // hit record (Solid.h:110-125)
+        d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0), refl = mk3(0, 0, 0);
+        int prim = -1;
+        rt_material m;
+        m.Ks = 0; m.T = 0; m.ior = 1;
+        if (hit) {
+            d3 nraw;
+            if (best & SLOT_SPHERE) {
+                const int s = best & ~SLOT_SPHERE;
+                prim = (int)(P.S.sph_prim[s] & ~RT_SPH_TRANSPARENT);
+                const rt_sph_rec *sp = &P.S.sph[s];
+                nraw = div3(sub3(add3(o, scale3(best_t, d)), ld3(sp->center)), sp->radius);
+            } else {
+                const rt_tri_rec *tr = &P.S.tri[best];
+                prim = tr->prim;
+                const double *pn = &P.S.prim_normals[(size_t)prim * 12];
+                nraw = ld3(pn);
+                if ((P.flags & RT_FLAG_PHONG_NORMALS) && (P.S.prim_flags[prim] & RT_PRIM_HAS_VNORMALS)) {
+                    double al, be;
+                    (void)tri_test(tr, o, d, .01, 10000000000.0, &al, &be);
+                    d3 n0 = ld3(pn + 3), n1 = ld3(pn + 6), n2 = ld3(pn + 9);
+                    nraw = add3(add3(scale3(al, n1), scale3(be, n2)), scale3(1 - (al + be), n0));
+                }
+            }
+            n = unit3(nraw);
+            Pt = mk3(o.x + d.x * best_t, o.y + d.y * best_t, o.z + d.z * best_t);
+            refl = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));
+            m = P.S.materials[P.S.prim_material[prim]];
+        }
+        if (PRIMARY && active && first_sample && P.hit_id) P.hit_id[pixel] = prim;
+
+        // hit queue for the shadow/shading pass
+        {
+            bool ok;
+            bool want = hit && P.S.n_lights > 0;
+            uint32_t slot = wave_reserve(want, &Q.counts[8 + Q.generation], Q.hit_capacity, &Q.counts[15], &ok);
+            if (ok) {
+                HitRec *h = &Q.hits[slot];
+                h->P[0] = Pt.x; h->P[1] = Pt.y; h->P[2] = Pt.z;
+                h->n[0] = n.x; h->n[1] = n.y; h->n[2] = n.z;
+                h->e[0] = o.x; h->e[1] = o.y; h->e[2] = o.z;
+                h->weight = wloc;
+                h->pixel = pixel;
+                h->prim = prim;
+            }
+        }
+
+        // secondary rays (Camera.h:244-307)
+        const bool spawn = hit && L > 0 && !(coef < .01);
+        {
+            bool want = spawn && m.T > 0;
+            bool ok;
+            uint32_t slot = wave_reserve(want, &Q.counts[Q.generation + 1], Q.ray_capacity, &Q.counts[15], &ok);
+            if (ok) {
+                double ior = m.ior;
+                d3 nn = n;
+                d3 V = neg3(d);
+                double dt = dot3(nn, V);
+                if (dt >= 0) ior = 1.0 / ior;
+                else { nn = neg3(nn); dt = -dt; }
+                double disc = 1 - (1 - (dt * dt)) * (ior * ior);
+                d3 rd;
+                if (disc > 0) {
+                    double sq = sqrt(disc);
+                    rd = mk3((nn.x * dt - V.x) * ior - nn.x * sq, (nn.y * dt - V.y) * ior - nn.y * sq,
+                             (nn.z * dt - V.z) * ior - nn.z * sq);
+                } else {
+                    rd = unit3(add3(d, scale3(2.0 * -dot3(d, nn), nn)));
+                }
+                RayRec *r = &Q.rays_out[slot];
+                r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
+                r->d[0] = rd.x; r->d[1] = rd.y; r->d[2] = rd.z;
+                r->A = A * m.T;
+                r->coef = m.T * coef;
+                r->pixel = pixel;
+                r->meta = (uint32_t)(L - 1) | 0x100u;
+            }
+        }
+        {
+            const double coef2 = coef * m.Ks;
+            bool want = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
+            bool ok;
+            uint32_t slot = wave_reserve(want, &Q.counts[Q.generation + 1], Q.ray_capacity, &Q.counts[15], &ok);
+            if (ok) {
+                RayRec *r = &Q.rays_out[slot];
+                r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
+                r->d[0] = refl.x; r->d[1] = refl.y; r->d[2] = refl.z;
+                r->A = A;
+                r->coef = coef2;
+                r->pixel = pixel;
+                r->meta = (uint32_t)(L - 1);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shadow(FrameParams P, QueueSet Q)
+{
+    const uint32_t n_hits = min(Q.counts[8 + Q.generation], Q.hit_capacity);
+    const long long total = (long long)n_hits * P.S.n_lights;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool cull = P.cull_shadow != 0;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
+        const uint32_t h = (uint32_t)(k / P.S.n_lights);
+        const int li = (int)(k - (long long)h * P.S.n_lights);
+        const HitRec *hr = &Q.hits[h];
+        const rt_light *lt = &P.S.lights[li];
+        const d3 Pt = ld3(hr->P);
+        const d3 lpos = ld3(lt->pos);
+        const d3 toL = sub3(lpos, Pt);
+        const d3 rd = unit3(toL);
+        const double maxT = norm3(toL) - .01;
+        bool only;
+        int closest;
+        bool occluded = trace_shadow(P.S, Pt, rd, hr->prim, maxT, cull, &only, &closest);
+        double kfac = .999999;
+        if (occluded && only) {
+            // shadowed by transparent spheres only: the reference consults its light camera here
+            if (P.lc_mask) P.lc_mask[hr->pixel] = 1;
+        }
+        if (occluded) continue;
+        const rt_material m = P.S.materials[P.S.prim_material[hr->prim]];
+        const d3 normal = unit3(ld3(hr->n));
+        d3 local = mk3(0, 0, 0);
+        if (m.Ks > 0) {
+            d3 nn = unit3(normal);
+            d3 v = unit3(sub3(ld3(hr->e), Pt));
+            d3 lDir = unit3(sub3(lpos, Pt));
+            d3 rdir = unit3(add3(neg3(lDir), scale3(2.0 * dot3(lDir, nn), nn)));
+            double a = dot3(rdir, v);
+            double pw = pow((a < 0.0) ? 0.0 : a, m.Shine);
+            double ik = lt->intensity * m.Ks;
+            d3 comp = mk3((ik * lt->color[0]) * pw, (ik * lt->color[1]) * pw, (ik * lt->color[2]) * pw);
+            local = add3(local, scale3(kfac, comp));
+        }
+        {
+            double a = dot3(unit3(sub3(lpos, Pt)), normal);
+            double dm = (a < 0.0) ? 0.0 : a;
+            double ik = lt->intensity * m.Kd;
+            d3 comp = mk3((ik * m.r) * dm, (ik * m.g) * dm, (ik * m.b) * dm);
+            local = add3(local, scale3(kfac, comp));
+        }
+        accum_add(P.accum, hr->pixel, hr->weight, local);
+    }
+}
+
+// totals[0]=closest rays, [1]=shadow rays, [2..7]=rays per generation, [8..13]=hits per generation, [15]=overflow
+__global__ void k_collect_counts(const uint32_t *counts, unsigned long long *totals, int n_lights)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long closest = 0, shadow = 0;
+    for (int g = 0; g < 6; ++g) { closest += counts[g]; totals[2 + g] += counts[g]; }
+    for (int g = 0; g < 6; ++g) { shadow += (unsigned long long)counts[8 + g] * n_lights; totals[8 + g] += counts[8 + g]; }
+    totals[0] += closest;
+    totals[1] += shadow;
+    totals[15] += counts[15];
+}
+
+__global__ __launch_bounds__(256) void k_finalize(const double *accum, long long n_values, int spp, double *out_f64,
+                                                  uint8_t *out_u8)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride) {
+        double c = accum[i] / (double)spp;
+        c = (c < 1.0) ? c : 1.0;        // std::min(1.0, c)
+        c = (0.0 < c) ? c : 0.0;        // std::max(0.0, c)
+        double v = c * 255;
+        if (out_f64) out_f64[i] = v;
+        if (out_u8) out_u8[i] = (uint8_t)(int)v;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // scene
+    DevScene S{};
+    std::vector<void *> scene_allocs;
+    bool has_scene = false;
+    bool any_transparent = false;          // any material with T > 0
+    bool any_transparent_sphere = false;
+    bool spheres_inside_root = true;       // every sphere lies inside the root cube
+    int32_t lightcam_samples = 150;
+    // frame resources (grow-only)
+    double *accum = nullptr; size_t accum_values = 0;
+    RayRec *rays[2] = {nullptr, nullptr}; size_t ray_capacity = 0;
+    HitRec *hits = nullptr; size_t hit_capacity = 0;
+    uint32_t *counts = nullptr;
+    unsigned long long *totals = nullptr;
+    void *stage[4] = {nullptr, nullptr, nullptr, nullptr}; size_t stage_bytes[4] = {0, 0, 0, 0};
+    int64_t batch_override = 0;
+    // pending async frame
+    bool pending = false;
+    uint32_t pending_flags = 0;
+    int pending_batches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_shadow;
+    size_t ev_closest_used = 0, ev_shadow_used = 0;
+    int cu_count = 256;
+};
+
+static int free_scene(rt_ctx *ctx)
+{
+    for (void *p : ctx->scene_allocs) (void)hipFree(p);
+    ctx->scene_allocs.clear();
+    ctx->has_scene = false;
+    return RT_OK;
+}
+
+template <typename T>
+static int upload(rt_ctx *ctx, const T *src, size_t n, const T **dst)
+{
+    *dst = nullptr;
+    size_t bytes = sizeof(T) * (n ? n : 1);
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    ctx->scene_allocs.push_back(p);
+    if (n) HIP_TRY(hipMemcpy(p, src, sizeof(T) * n, hipMemcpyHostToDevice));
+    *dst = static_cast<const T *>(p);
+    return RT_OK;
+}
+
+extern "C" int rt_device_count(int *count)
+{
+    if (!count) return fail(RT_ERR_INVALID, "rt_device_count: null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(RT_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = n;
+    return RT_OK;
+}
+
+extern "C" int rt_create(int device_id, rt_ctx **out)
+{
+    if (!out) return fail(RT_ERR_INVALID, "rt_create: null argument");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (n <= 0) return fail(RT_ERR_DEVICE, "rt_create: no HIP device visible; this library has no CPU path");
+    if (device_id < 0 || device_id >= n) return fail(RT_ERR_INVALID, "rt_create: device_id out of range");
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    rt_ctx *ctx = new rt_ctx();
+    ctx->device = device_id;
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ctx->ev_begin));
+    HIP_TRY(hipEventCreate(&ctx->ev_end));
+    HIP_TRY(hipMalloc((void **)&ctx->counts, 16 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->totals, 16 * sizeof(unsigned long long)));
+    *out = ctx;
+    return RT_OK;
+}
+
+extern "C" int rt_destroy(rt_ctx *ctx)
+{
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    (void)hipFree(ctx->accum);
+    (void)hipFree(ctx->rays[0]);
+    (void)hipFree(ctx->rays[1]);
+    (void)hipFree(ctx->hits);
+    (void)hipFree(ctx->counts);
+    (void)hipFree(ctx->totals);
+    for (void *p : ctx->stage) (void)hipFree(p);
+    for (auto &pr : ctx->ev_closest) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &pr : ctx->ev_shadow) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    (void)hipEventDestroy(ctx->ev_begin);
+    (void)hipEventDestroy(ctx->ev_end);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+extern "C" int rt_set_batch(rt_ctx *ctx, int64_t primaries)
+{
+    if (!ctx || primaries < 0) return fail(RT_ERR_INVALID, "rt_set_batch: bad argument");
+    ctx->batch_override = primaries;
+    return RT_OK;
+}
+
+// Validates every index the kernels will follow, so that a malformed scene is an error
+// code here and never an out-of-bounds access on the GPU.
+static int validate_scene(const rt_scene_desc *s)
+{
+    if (!s->nodes || s->n_nodes <= 0) return fail(RT_ERR_INVALID, "scene: no nodes");
+    if (s->n_tri_slots < 0 || s->n_sph_slots < 0 || s->n_prims < 0 || s->n_materials <= 0 || s->n_lights < 0)
+        return fail(RT_ERR_INVALID, "scene: negative count");
+    if ((s->n_tri_slots && !s->tri) || (s->n_sph_slots && (!s->sph || !s->sph_prim)))
+        return fail(RT_ERR_INVALID, "scene: missing primitive records");
+    if (s->n_prims && (!s->prim_flags || !s->prim_material || !s->prim_normals))
+        return fail(RT_ERR_INVALID, "scene: missing per-primitive arrays");
+    if (!s->materials || (s->n_lights && !s->lights)) return fail(RT_ERR_INVALID, "scene: missing materials or lights");
+    for (int32_t i = 0; i < s->n_nodes; ++i) {
+        const rt_node &n = s->nodes[i];
+        if (n.skip <= i || n.skip > s->n_nodes) return fail(RT_ERR_INVALID, "scene: node skip link out of order");
+        if (n.tri_count < 0 || n.tri_begin < 0 || (int64_t)n.tri_begin + n.tri_count > s->n_tri_slots)
+            return fail(RT_ERR_INVALID, "scene: node triangle range out of bounds");
+        if (n.sph_count < 0 || n.sph_begin < 0 || (int64_t)n.sph_begin + n.sph_count > s->n_sph_slots)
+            return fail(RT_ERR_INVALID, "scene: node sphere range out of bounds");
+    }
+    for (int32_t i = 0; i < s->n_tri_slots; ++i)
+        if (s->tri[i].prim < 0 || s->tri[i].prim >= s->n_prims || (s->prim_flags[s->tri[i].prim] & RT_PRIM_SPHERE))
+            return fail(RT_ERR_INVALID, "scene: triangle slot names a bad primitive");
+    for (int32_t i = 0; i < s->n_sph_slots; ++i) {
+        uint32_t p = s->sph_prim[i] & ~RT_SPH_TRANSPARENT;
+        if (p >= (uint32_t)s->n_prims || !(s->prim_flags[p] & RT_PRIM_SPHERE))
+            return fail(RT_ERR_INVALID, "scene: sphere slot names a bad primitive");
+    }
+    for (int32_t i = 0; i < s->n_prims; ++i)
+        if (s->prim_material[i] < 0 || s->prim_material[i] >= s->n_materials)
+            return fail(RT_ERR_INVALID, "scene: primitive material out of range");
+    return RT_OK;
+}
+
+extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
+{
+    if (!ctx || !s) return fail(RT_ERR_INVALID, "rt_upload_scene: null argument");
+    int rc = validate_scene(s);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+    DevScene D{};
+    if ((rc = upload(ctx, s->nodes, (size_t)s->n_nodes, &D.nodes)) != RT_OK) return rc;
+    if ((rc = upload(ctx, s->tri, (size_t)s->n_tri_slots, &D.tri)) != RT_OK) return rc;
+    if ((rc = upload(ctx, s->sph, (size_t)s->n_sph_slots, &D.sph)) != RT_OK) return rc;
+    if ((rc = upload(ctx, s->sph_prim, (size_t)s->n_sph_slots, &D.sph_prim)) != RT_OK) return rc;
+    if ((rc = upload(ctx, s->prim_flags, (size_t)s->n_prims, &D.prim_flags)) != RT_OK) return rc;
+    if ((rc = upload(ctx, s->prim_material, (size_t)s->n_prims, &D.prim_material)) != RT_OK) return rc;
+    if ((rc = upload(ctx, s->prim_normals, (size_t)s->n_prims * 12, &D.prim_normals)) != RT_OK) return rc;
+    if ((rc = upload(ctx, s->materials, (size_t)s->n_materials, &D.materials)) != RT_OK) return rc;
+    if ((rc = upload(ctx, s->lights, (size_t)s->n_lights, &D.lights)) != RT_OK) return rc;
+    D.n_nodes = s->n_nodes;
+    D.n_lights = s->n_lights;
+    D.bg[0] = s->background[0]; D.bg[1] = s->background[1]; D.bg[2] = s->background[2];
+    ctx->S = D;
+    ctx->lightcam_samples = s->lightcam_samples;
+    ctx->any_transparent = false;
+    for (int32_t i = 0; i < s->n_materials; ++i) if (s->materials[i].T > 0) ctx->any_transparent = true;
+    ctx->any_transparent_sphere = false;
+    for (int32_t i = 0; i < s->n_sph_slots; ++i) if (s->sph_prim[i] & RT_SPH_TRANSPARENT) ctx->any_transparent_sphere = true;
+    // Pruning by entry distance is only result-preserving when every sphere surface point
+    // lies inside the root cube (then some leaf that contains the hit point also holds the sphere).
+    ctx->spheres_inside_root = true;
+    const rt_node &root = s->nodes[0];
+    const double half = root.radius / (std::sqrt(3.0) / 2.0) / 2.0;
+    for (int32_t i = 0; i < s->n_sph_slots; ++i)
+        for (int k = 0; k < 3; ++k) {
+            double c = s->sph[i].center[k] - root.center[k];
+            if (!(std::fabs(c) + s->sph[i].radius < half * (1.0 - 1e-9))) ctx->spheres_inside_root = false;
+        }
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+static int local_rows_of(const rt_camera *cam, const rt_render_opts *o)
+{
+    int band = o->band_rows > 0 ? o->band_rows : cam->resy;
+    int parts = o->n_parts > 0 ? o->n_parts : 1;
+    int rows = 0;
+    int n_bands = (cam->resy + band - 1) / band;
+    for (int b = o->part; b < n_bands; b += parts) {
+        int r0 = b * band, r1 = r0 + band;
+        if (r1 > cam->resy) r1 = cam->resy;
+        rows += r1 - r0;
+    }
+    return rows;
+}
+
+extern "C" int rt_part_rows(const rt_camera *cam, const rt_render_opts *opts, int32_t *rows)
+{
+    if (!cam || !opts || !rows) return fail(RT_ERR_INVALID, "rt_part_rows: null argument");
+    if (cam->resx <= 0 || cam->resy <= 0) return fail(RT_ERR_INVALID, "rt_part_rows: empty frame");
+    int parts = opts->n_parts > 0 ? opts->n_parts : 1;
+    if (opts->part < 0 || opts->part >= parts) return fail(RT_ERR_INVALID, "rt_part_rows: part out of range");
+    *rows = local_rows_of(cam, opts);
+    return RT_OK;
+}
+
+template <typename T>
+static int ensure(T **ptr, size_t *have, size_t want)
+{
+    if (*have >= want && *ptr) return RT_OK;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc((void **)ptr, sizeof(T) * want));
+    *have = want;
+    return RT_OK;
+}
+
+static std::pair<hipEvent_t, hipEvent_t> *next_event_pair(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, size_t &used)
+{
+    if (used == v.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+        v.emplace_back(a, b);
+    }
+    return &v[used++];
+}
+
+static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *o, const rt_frame_out *out,
+                         bool outputs_on_device)
+{
+    if (!ctx || !cam || !o || !out) return fail(RT_ERR_INVALID, "rt_render: null argument");
+    if (!ctx->has_scene) return fail(RT_ERR_INVALID, "rt_render: no scene uploaded");
+    if (cam->resx <= 0 || cam->resy <= 0) return fail(RT_ERR_INVALID, "rt_render: empty frame");
+    if (o->num_samples < 1 || o->num_samples > 64) return fail(RT_ERR_INVALID, "rt_render: num_samples must be in 1..64");
+    const int parts = o->n_parts > 0 ? o->n_parts : 1;
+    const int band = o->band_rows > 0 ? o->band_rows : cam->resy;
+    if (o->part < 0 || o->part >= parts) return fail(RT_ERR_INVALID, "rt_render: part out of range");
+    if (ctx->pending) return fail(RT_ERR_INVALID, "rt_render: a frame is already in flight; call rt_sync first");
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    const int local_rows = local_rows_of(cam, o);
+    const int N = o->num_samples;
+    const size_t n_pixels = (size_t)local_rows * cam->resx;
+    if (n_pixels >= (size_t)1 << 31) return fail(RT_ERR_INVALID, "rt_render: more than 2^31 pixels in one part");
+
+    FrameParams P{};
+    P.S = ctx->S;
+    P.cam = *cam;
+    P.N = N;
+    P.aperture = o->aperture;
+    P.flags = o->flags;
+    P.seed = o->seed;
+    P.band_rows = band;
+    P.n_parts = parts;
+    P.part = o->part;
+    P.local_rows = local_rows;
+    P.tiles_x = (cam->resx * N + 7) / 8;
+    const bool may_cull = !(o->flags & RT_FLAG_NO_CULL) && ctx->spheres_inside_root;
+    P.cull_closest = may_cull ? 1 : 0;
+    P.cull_shadow = (may_cull && !ctx->any_transparent_sphere) ? 1 : 0;
+
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipEventRecord(ctx->ev_begin, st));
+    HIP_TRY(hipMemsetAsync(ctx->totals, 0, 16 * sizeof(unsigned long long), st));
+    ctx->ev_closest_used = ctx->ev_shadow_used = 0;
+    ctx->pending_flags = o->flags;
+    ctx->pending_batches = 0;
+
+    if (local_rows > 0) {
+        int rc;
+        if ((rc = ensure(&ctx->accum, &ctx->accum_values, n_pixels * 3)) != RT_OK) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->accum, 0, n_pixels * 3 * sizeof(double), st));
+        P.accum = ctx->accum;
+
+        // outputs: device pointers are used directly, host pointers go through staging buffers
+        void *dst[4] = {out->rgb_f64, out->rgb_u8, out->hit_id, out->lightcam_mask};
+        const size_t bytes[4] = {n_pixels * 3 * sizeof(double), n_pixels * 3, n_pixels * sizeof(int32_t), n_pixels};
+        void *dev[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < 4; ++k) {
+            if (!dst[k]) continue;
+            if (outputs_on_device) dev[k] = dst[k];
+            else {
+                if (ctx->stage_bytes[k] < bytes[k]) {
+                    if (ctx->stage[k]) HIP_TRY(hipFree(ctx->stage[k]));
+                    ctx->stage[k] = nullptr; ctx->stage_bytes[k] = 0;
+                    HIP_TRY(hipMalloc(&ctx->stage[k], bytes[k]));
+                    ctx->stage_bytes[k] = bytes[k];
+                }
+                dev[k] = ctx->stage[k];
+            }
+        }
+        P.hit_id = static_cast<int32_t *>(dev[2]);
+        P.lc_mask = static_cast<uint8_t *>(dev[3]);
+        if (dev[3]) HIP_TRY(hipMemsetAsync(dev[3], 0, bytes[3], st));
+
+        const long long tiles_y = ((long long)local_rows * N + 7) / 8;
+        const long long n_tiles = tiles_y * P.tiles_x;
+        // queue sizing: a generation has at most fan^g rays per primary sample
+        const long long fan = ctx->any_transparent ? 32 : 1;
+        long long batch_tiles = ctx->batch_override > 0 ? (ctx->batch_override + 63) / 64
+                                                         : (ctx->any_transparent ? (1ll << 21) / 64 : (1ll << 23) / 64);
+        if (batch_tiles > n_tiles) batch_tiles = n_tiles;
+        if (batch_tiles < 1) batch_tiles = 1;
+        const size_t cap = (size_t)(batch_tiles * 64 * fan);
+        if (cap >= ((size_t)1 << 32) - 64) return fail(RT_ERR_INVALID, "rt_render: batch too large for 32-bit queue indices");
+        size_t have0 = ctx->ray_capacity, have1 = ctx->ray_capacity;
+        if ((rc = ensure(&ctx->rays[0], &have0, cap)) != RT_OK) return rc;
+        if ((rc = ensure(&ctx->rays[1], &have1, cap)) != RT_OK) return rc;
+        ctx->ray_capacity = have0 < have1 ? have0 : have1;
+        if ((rc = ensure(&ctx->hits, &ctx->hit_capacity, cap)) != RT_OK) return rc;
+
+        const bool timing = (o->flags & RT_FLAG_TIMING) != 0;
+        const int max_blocks = ctx->cu_count * 8;
+        for (long long t0 = 0; t0 < n_tiles; t0 += batch_tiles) {
+            const long long t1 = (t0 + batch_tiles < n_tiles) ? t0 + batch_tiles : n_tiles;
+            HIP_TRY(hipMemsetAsync(ctx->counts, 0, 16 * sizeof(uint32_t), st));
+            for (int g = 0; g < 6; ++g) {
+                QueueSet Q{};
+                Q.rays_in = ctx->rays[g & 1];
+                Q.rays_out = ctx->rays[(g + 1) & 1];
+                Q.hits = ctx->hits;
+                Q.counts = ctx->counts;
+                Q.ray_capacity = (uint32_t)cap;
+                Q.hit_capacity = (uint32_t)cap;
+                Q.generation = g;
+                Q.tile_begin = t0;
+                Q.tile_end = t1;
+                std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+                if (timing && !(ev = next_event_pair(ctx->ev_closest, ctx->ev_closest_used)))
+                    return fail(RT_ERR_DEVICE, "hipEventCreate failed");
+                if (ev) HIP_TRY(hipEventRecord(ev->first, st));
+                if (g == 0) {
+                    long long blocks = (t1 - t0 + 3) / 4;
+                    if (blocks > max_blocks) blocks = max_blocks;
+                    hipLaunchKernelGGL(k_closest<true>, dim3((unsigned)blocks), dim3(256), 0, st, P, Q);
+                } else {
+                    hipLaunchKernelGGL(k_closest<false>, dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
+                }
+                if (ev) HIP_TRY(hipEventRecord(ev->second, st));
+                if (P.S.n_lights > 0) {
+                    ev = nullptr;
+                    if (timing && !(ev = next_event_pair(ctx->ev_shadow, ctx->ev_shadow_used)))
+                        return fail(RT_ERR_DEVICE, "hipEventCreate failed");
+                    if (ev) HIP_TRY(hipEventRecord(ev->first, st));
+                    hipLaunchKernelGGL(k_shadow, dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
+                    if (ev) HIP_TRY(hipEventRecord(ev->second, st));
+                }
+            }
+            hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, ctx->counts, ctx->totals, P.S.n_lights);
+            ctx->pending_batches++;
+        }
+        HIP_TRY(hipGetLastError());
+        {
+            const long long n_values = (long long)n_pixels * 3;
+            long long blocks = (n_values + 255) / 256;
+            if (blocks > max_blocks) blocks = max_blocks;
+            hipLaunchKernelGGL(k_finalize, dim3((unsigned)blocks), dim3(256), 0, st, ctx->accum, n_values, N * N,
+                               static_cast<double *>(dev[0]), static_cast<uint8_t *>(dev[1]));
+            HIP_TRY(hipGetLastError());
+        }
+        if (!outputs_on_device)
+            for (int k = 0; k < 4; ++k)
+                if (dst[k]) HIP_TRY(hipMemcpyAsync(dst[k], dev[k], bytes[k], hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipEventRecord(ctx->ev_end, st));
+    ctx->pending = true;
+    return RT_OK;
+}
+
+extern "C" int rt_sync(rt_ctx *ctx, rt_stats *stats)
+{
+    if (!ctx) return fail(RT_ERR_INVALID, "rt_sync: null argument");
+    if (!ctx->pending) return fail(RT_ERR_INVALID, "rt_sync: no frame in flight");
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctx->pending = false;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long tot[16];
+    HIP_TRY(hipMemcpy(tot, ctx->totals, sizeof tot, hipMemcpyDeviceToHost));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->closest_rays = tot[0];
+        stats->shadow_rays = tot[1];
+        for (int g = 0; g < 6; ++g) { stats->rays_per_generation[g] = tot[2 + g]; stats->hits_per_generation[g] = tot[8 + g]; }
+        stats->queue_overflow = tot[15] ? 1 : 0;
+        stats->batches = ctx->pending_batches;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        stats->gpu_ms = ms;
+        if (ctx->pending_flags & RT_FLAG_TIMING) {
+            double c = 0, s = 0;
+            for (size_t i = 0; i < ctx->ev_closest_used; ++i) {
+                float m = 0;
+                HIP_TRY(hipEventElapsedTime(&m, ctx->ev_closest[i].first, ctx->ev_closest[i].second));
+                c += m;
+            }
+            for (size_t i = 0; i < ctx->ev_shadow_used; ++i) {
+                float m = 0;
+                HIP_TRY(hipEventElapsedTime(&m, ctx->ev_shadow[i].first, ctx->ev_shadow[i].second));
+                s += m;
+            }
+            stats->closest_ms = c;
+            stats->shadow_ms = s;
+            stats->other_ms = ms - c - s;
+            stats->closest_launches = ctx->ev_closest_used;
+            stats->shadow_launches = ctx->ev_shadow_used;
+        }
+    }
+    if (tot[15]) return fail(RT_ERR_CAPACITY, "rt_render: a ray queue overflowed; the frame is incomplete");
+    return RT_OK;
+}
+
+extern "C" int rt_render_async(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *opts, const rt_frame_out *out)
+{
+    if (out && !out->on_device) return fail(RT_ERR_INVALID, "rt_render_async: outputs must be device memory");
+    return enqueue_frame(ctx, cam, opts, out, true);
+}
+
+extern "C" int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *opts, const rt_frame_out *out,
+                         rt_stats *stats)
+{
+    int rc = enqueue_frame(ctx, cam, opts, out, out && out->on_device);
+    if (rc != RT_OK) {
+        if (ctx) { (void)hipStreamSynchronize(ctx->stream); ctx->pending = false; }
+        return rc;
+    }
+    return rt_sync(ctx, stats);
+}

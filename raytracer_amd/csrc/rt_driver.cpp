@@ -1,0 +1,68 @@
+// Command-line host with the reference's interface (Driver.cpp:91-216):
+//     rt_driver [-s N] [-a A] [-p] input.nff output.ppm
+// Parses the scene, builds the octree, renders on GPU 0 through the C ABI and writes
+// a binary PPM.  Unlike the reference (Driver.cpp:727) the output argument is honoured;
+// pass `hide.ppm` to get the reference's file name.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/raytracer_amd.h"
+
+static long long now_ms()
+{
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+#define CHECK(call)                                                        \
+    do {                                                                   \
+        if ((call) != RT_OK) {                                             \
+            std::fprintf(stderr, "%s failed: %s\n", #call, rt_last_error()); \
+            return 1;                                                      \
+        }                                                                  \
+    } while (0)
+
+int main(int argc, char **argv)
+{
+    int32_t num_samples = 1, phong = 0;
+    double aperture = 0;
+    char in_path[4096], out_path[4096];
+    CHECK(rth_parse_args(argc, argv, &num_samples, &aperture, &phong, in_path, sizeof in_path, out_path, sizeof out_path));
+    std::printf("Arguments recieved:\nNum samples = %d\nAperture = %f\nPhong = %d\n", num_samples, aperture, phong);
+
+    long long t1 = now_ms();
+    rth_scene *scene = nullptr;
+    CHECK(rth_scene_load(in_path, &scene));
+    rt_scene_desc desc;
+    CHECK(rth_scene_desc(scene, &desc));
+    rt_camera cam;
+    CHECK(rth_scene_camera(scene, 0, 0, &cam));
+    long long t2 = now_ms();
+    std::printf("Nff parsing, polygon construction and octree construction took %lld ms\n", t2 - t1);
+    std::printf("There are %d total solids in the scene.\nThere are %d octrees!\n", desc.n_prims, desc.n_nodes);
+
+    rt_ctx *ctx = nullptr;
+    CHECK(rt_create(0, &ctx));
+    CHECK(rt_upload_scene(ctx, &desc));
+
+    rt_render_opts opts = {};
+    opts.num_samples = num_samples;
+    opts.aperture = aperture;
+    opts.flags = phong ? RT_FLAG_PHONG_NORMALS : 0u;
+    opts.n_parts = 1;
+    std::vector<double> pixels(static_cast<size_t>(cam.resx) * cam.resy * 3);
+    rt_frame_out out = {};
+    out.rgb_f64 = pixels.data();
+    rt_stats stats;
+    t1 = now_ms();
+    CHECK(rt_render(ctx, &cam, &opts, &out, &stats));
+    t2 = now_ms();
+    std::printf("Render took %lld ms (GPU %.3f ms; %llu closest + %llu shadow rays, %.1f Mrays/s)\n", t2 - t1, stats.gpu_ms,
+                (unsigned long long)stats.closest_rays, (unsigned long long)stats.shadow_rays,
+                (stats.closest_rays + stats.shadow_rays) / (stats.gpu_ms * 1e3));
+    CHECK(rth_write_ppm_f64(out_path, pixels.data(), cam.resx, cam.resy));
+    rt_destroy(ctx);
+    rth_scene_free(scene);
+    return 0;
+}

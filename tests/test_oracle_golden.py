@@ -1,0 +1,94 @@
+"""Pins the CPU oracle to what the reference itself holds or produced.
+
+* hide.ppm -- the one golden image in the reference checkout (its render of glass.nff,
+  including the light-camera caustics): the oracle's glass.nff frame must be
+  byte-identical.
+* golden.json "reference_runs" -- sha256 prefixes, octree sizes and ray counts recorded from
+  a run of the reference binary on tetra-3, teapot-3 (flat and -p), balls and refract.
+"""
+import gzip
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def ppm_bytes(rgb_f64):
+    h, w, _ = rgb_f64.shape
+    body = rgb_f64.astype(np.int32).astype(np.uint8).tobytes()
+    return b"P6\n%d %d\n%d\n" % (w, h, 255) + body
+
+
+def test_hide_ppm_byte_identical(golden, oracle_frame):
+    with gzip.open(os.path.join(GOLDEN_DIR, "hide.ppm.gz"), "rb") as f:
+        ref = f.read()
+    assert hashlib.sha256(ref).hexdigest() == golden["hide_ppm_sha256"]
+    fr = oracle_frame("glass")
+    mine = ppm_bytes(fr["rgb_f64"])
+    assert len(mine) == len(ref)
+    assert mine == ref, "oracle glass.nff render differs from the reference's hide.ppm"
+    run = golden["reference_runs"]["glass"]
+    assert fr["counters"]["closest_rays"] == run["closest"]
+    assert fr["counters"]["shadow_rays"] == run["shadow"]
+    # four (transparent sphere, light) pairs, Z*Z top-level light rays each
+    assert len(fr["lightcams"]) == 4
+    assert fr["counters"]["lightcam_queries"] > 0
+
+
+@pytest.mark.parametrize("scene", ["tetra-3", "teapot-3", "balls", "refract"])
+def test_reference_run_checksums(golden, oracle_frame, oracle_mod, scene):
+    run = golden["reference_runs"][scene]
+    o = oracle_mod.OracleScene(rt.scene_path(scene))
+    assert [o.resx, o.resy] == run["res"]
+    assert o.n_solids == run["solids"]
+    assert o.n_nodes == run["nodes"]
+    o.close()
+    fr = oracle_frame(scene)
+    assert hashlib.sha256(ppm_bytes(fr["rgb_f64"])).hexdigest()[:12] == run["sha12"]
+    assert fr["counters"]["closest_rays"] == run["closest"]
+    assert fr["counters"]["shadow_rays"] == run["shadow"]
+
+
+def test_reference_run_phong_normals(golden, oracle_frame):
+    run = golden["reference_runs"]["teapot-3"]
+    fr = oracle_frame("teapot-3", phong=True)
+    assert hashlib.sha256(ppm_bytes(fr["rgb_f64"])).hexdigest()[:12] == run["sha12_phong"]
+
+
+def test_oracle_ppm_writer(tmp_path, oracle_mod, oracle_frame):
+    import ctypes as C
+    fr = oracle_frame("tetra-3")
+    px = np.ascontiguousarray(fr["rgb_f64"])
+    path = str(tmp_path / "o.ppm")
+    oracle_mod.load().orc_write_ppm(px.ctypes.data_as(C.POINTER(C.c_double)), px.shape[1], px.shape[0], path.encode())
+    with open(path, "rb") as f:
+        assert f.read() == ppm_bytes(px)
+
+
+def test_primitive_edge_cases(oracle_mod):
+    tri = [0, 0, 0, 1, 0, 0, 0, 1, 0]
+    # ray parallel to the plane: detA = 0, every ratio is NaN or inf and the test reports a miss
+    t, _ = oracle_mod.test_triangle(tri, [1, 0, 0], [0, 0, 1], .01, 1e10)
+    assert t == 1e10
+    # straight down onto the interior
+    t, out = oracle_mod.test_triangle(tri, [0, 0, -1], [.25, .25, 2], .01, 1e10)
+    assert t == 2.0 and abs(abs(out[3]) - 1.0) < 1e-15
+    # closer than minT is rejected
+    t, _ = oracle_mod.test_triangle(tri, [0, 0, -1], [.25, .25, .005], .01, 1e10)
+    assert t == 1e10
+    # sphere from inside: the far root is taken, the normal still points outward
+    t, out = oracle_mod.test_sphere([0, 0, 0], 1.0, [1, 0, 0], [0, 0, 0], .01, 1e10)
+    assert t == 1.0 and out[1] == 1.0
+    # sphere behind the origin
+    t, _ = oracle_mod.test_sphere([-5, 0, 0], 1.0, [1, 0, 0], [0, 0, 0], .01, 1e10)
+    assert t == 1e10
+    # node bound (Sphere.h:182-195 takes sqrt(B*B-4AC) without halving it, so the roots are
+    # -b +- 2*sqrt(b*b-AC): a looser sphere than the node's; the oracle keeps that):
+    # origin inside -> far root; miss -> sentinel
+    assert oracle_mod.test_bound([0, 0, 0], 2.0, [0, 1, 0], [0, 0, 0], .01, 1e7) == 4.0
+    assert oracle_mod.test_bound([0, 0, 0], 2.0, [0, 1, 0], [5, 0, 0], .01, 1e7) == 1e7
