@@ -51,14 +51,20 @@ def build_library(force=False):
     host_src = os.path.join(CSRC, "host_scene.cpp")
     header = os.path.join(ROOT, "include", "raytracer_amd.h")
     deps = [dev_src, host_src, header, os.path.join(CSRC, "host_scene.hpp"), os.path.abspath(__file__)]
+    accel_src = os.path.join(CSRC, "accel_build.cpp")
+    accel_hdr = os.path.join(CSRC, "accel_build.hpp")
+    deps += [accel_src, accel_hdr]
     dev_obj = os.path.join(CSRC, "rt_device.o")
     host_obj = os.path.join(CSRC, "host_scene.o")
-    if force or _newer(dev_obj, [dev_src, header, os.path.abspath(__file__)]):
+    accel_obj = os.path.join(CSRC, "accel_build.o")
+    if force or _newer(dev_obj, [dev_src, header, accel_hdr, os.path.abspath(__file__)]):
         _run([hipcc] + DEVICE_FLAGS + ["-c", dev_src, "-o", dev_obj])
     if force or _newer(host_obj, [host_src, header, os.path.join(CSRC, "host_scene.hpp"), os.path.abspath(__file__)]):
         _run(["g++"] + HOST_FLAGS + ["-c", host_src, "-o", host_obj])
-    if force or _newer(LIB, deps + [dev_obj, host_obj]):
-        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, dev_obj, host_obj])
+    if force or _newer(accel_obj, [accel_src, accel_hdr, header, os.path.abspath(__file__)]):
+        _run(["g++"] + HOST_FLAGS + ["-c", accel_src, "-o", accel_obj])
+    if force or _newer(LIB, deps + [dev_obj, host_obj, accel_obj]):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, dev_obj, host_obj, accel_obj])
     return LIB
 
 

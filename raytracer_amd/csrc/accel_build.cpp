@@ -1,0 +1,272 @@
+// Bounding-volume hierarchies derived from the flattened octree (see accel_build.hpp).
+//
+// Why the answer cannot change.  The reference's closest-hit query (Octree.h:996-1062)
+// tests a primitive only if every node on the path from the root to a node that holds it
+// passes the bounding-sphere test (Sphere.h:155-204).  A triangle is resident in a node only
+// if it lies inside that node's cube (Triangle.h:359-374), and a sphere is handed down to
+// every child cube it overlaps (Sphere.h:211-232) until subdivision stops; so for any hit
+// point inside the root cube there is a node holding the primitive whose cube, and every
+// ancestor's cube, contains the hit point -- and a ray that reaches a point inside a cube
+// passes that cube's bounding-sphere test.  Hence, once the root's own test has passed, the
+// reference's result is "nearest intersection over all primitives", ties going to the
+// primitive met first in its depth-first order.  The hierarchies below answer exactly that,
+// with the tie rule carried as an explicit key.  The premise "every hit point lies inside
+// the root cube" is checked for spheres at upload (triangles outside the cube stay resident
+// in the root, whose test is evaluated per ray on the device); when it fails the device keeps
+// to the octree walk.
+#include "accel_build.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace accel {
+namespace {
+
+struct Item {
+    double lo[3], hi[3], c[3];
+    int32_t src;   // index into the source record array
+};
+
+struct Box {
+    double lo[3], hi[3];
+    void reset()
+    {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::numeric_limits<double>::infinity(); hi[k] = -lo[k]; }
+    }
+    void grow(const double *l, const double *h)
+    {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]); }
+    }
+    double area() const
+    {
+        double e[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        if (e[0] < 0 || e[1] < 0 || e[2] < 0) return 0;
+        return 2 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
+    }
+};
+
+constexpr int kLeafMax = 4;
+constexpr int kBins = 16;
+constexpr int kSahDepth = 14;   // below this depth splits are medians, which bounds the tree height
+
+class Builder {
+public:
+    Builder(std::vector<Item> &items, Bvh &out) : it_(items), out_(out) {}
+
+    void run()
+    {
+        out_.nodes.clear();
+        out_.max_depth = 0;
+        const int n = static_cast<int>(it_.size());
+        if (n == 0) return;
+        if (n <= kLeafMax) {   // a root whose first child is the only leaf
+            BvhNode root = empty_node();
+            set_leaf(root, 0, 0, n);
+            out_.nodes.push_back(root);
+            out_.max_depth = 1;
+            return;
+        }
+        split(0, n, 1);
+    }
+
+private:
+    static BvhNode empty_node()
+    {
+        BvhNode nd;
+        std::memset(&nd, 0, sizeof nd);
+        for (int s = 0; s < 2; ++s) {
+            nd.child[s] = -1;
+            for (int k = 0; k < 3; ++k) { nd.lo[s][k] = 1.0; nd.hi[s][k] = -1.0; }
+        }
+        return nd;
+    }
+
+    Box bounds(int b, int e) const
+    {
+        Box bx;
+        bx.reset();
+        for (int i = b; i < e; ++i) bx.grow(it_[i].lo, it_[i].hi);
+        return bx;
+    }
+
+    // Boxes are pushed outward so that the slab test on the device is conservative with
+    // respect to the FP64 primitive tests it guards.
+    static void store_box(BvhNode &nd, int side, const Box &bx)
+    {
+        for (int k = 0; k < 3; ++k) {
+            double scale = std::max({1.0, std::fabs(bx.lo[k]), std::fabs(bx.hi[k]), bx.hi[k] - bx.lo[k]});
+            nd.lo[side][k] = bx.lo[k] - 1e-7 * scale;
+            nd.hi[side][k] = bx.hi[k] + 1e-7 * scale;
+        }
+    }
+
+    void set_leaf(BvhNode &nd, int side, int b, int e)
+    {
+        store_box(nd, side, bounds(b, e));
+        nd.child[side] = b;
+        nd.count[side] = e - b;
+    }
+
+    int choose_split(int b, int e, int depth)
+    {
+        const int n = e - b;
+        Box cb;
+        cb.reset();
+        for (int i = b; i < e; ++i) cb.grow(it_[i].c, it_[i].c);
+        int axis = 0;
+        for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+        auto median = [&](int ax) {
+            const int mid = b + n / 2;
+            std::nth_element(it_.begin() + b, it_.begin() + mid, it_.begin() + e,
+                             [ax](const Item &x, const Item &y) { return x.c[ax] < y.c[ax] || (x.c[ax] == y.c[ax] && x.src < y.src); });
+            return mid;
+        };
+        if (depth >= kSahDepth || !(cb.hi[axis] - cb.lo[axis] > 0)) return median(axis);
+
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_axis = -1, best_bin = -1;
+        for (int ax = 0; ax < 3; ++ax) {
+            const double ext = cb.hi[ax] - cb.lo[ax];
+            if (!(ext > 0)) continue;
+            Box bin_box[kBins];
+            int bin_n[kBins] = {0};
+            for (auto &bb : bin_box) bb.reset();
+            for (int i = b; i < e; ++i) {
+                int k = static_cast<int>(kBins * ((it_[i].c[ax] - cb.lo[ax]) / ext));
+                k = std::min(std::max(k, 0), kBins - 1);
+                bin_box[k].grow(it_[i].lo, it_[i].hi);
+                bin_n[k]++;
+            }
+            double right_area[kBins];
+            int right_n[kBins];
+            Box acc;
+            acc.reset();
+            int cnt = 0;
+            for (int k = kBins - 1; k > 0; --k) {
+                if (bin_n[k]) acc.grow(bin_box[k].lo, bin_box[k].hi);
+                cnt += bin_n[k];
+                right_area[k] = acc.area();
+                right_n[k] = cnt;
+            }
+            acc.reset();
+            cnt = 0;
+            for (int k = 0; k < kBins - 1; ++k) {
+                if (bin_n[k]) acc.grow(bin_box[k].lo, bin_box[k].hi);
+                cnt += bin_n[k];
+                if (cnt == 0 || right_n[k + 1] == 0) continue;
+                double cost = acc.area() * cnt + right_area[k + 1] * right_n[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = k; }
+            }
+        }
+        if (best_axis < 0) return median(axis);
+        const double ext = cb.hi[best_axis] - cb.lo[best_axis];
+        const double lo = cb.lo[best_axis];
+        auto mid_it = std::partition(it_.begin() + b, it_.begin() + e, [&](const Item &x) {
+            int k = static_cast<int>(kBins * ((x.c[best_axis] - lo) / ext));
+            k = std::min(std::max(k, 0), kBins - 1);
+            return k <= best_bin;
+        });
+        int mid = static_cast<int>(mid_it - it_.begin());
+        if (mid == b || mid == e) return median(axis);
+        return mid;
+    }
+
+    // Builds the node for [b,e) (more than kLeafMax items) and returns its index.
+    int split(int b, int e, int depth)
+    {
+        out_.max_depth = std::max(out_.max_depth, depth);
+        const int me = static_cast<int>(out_.nodes.size());
+        out_.nodes.push_back(empty_node());
+        const int mid = choose_split(b, e, depth);
+        const int rb[2] = {b, mid}, re[2] = {mid, e};
+        for (int s = 0; s < 2; ++s) {
+            if (re[s] - rb[s] <= kLeafMax) {
+                BvhNode nd = out_.nodes[me];
+                set_leaf(nd, s, rb[s], re[s]);
+                out_.nodes[me] = nd;
+                out_.max_depth = std::max(out_.max_depth, depth + 1);
+            } else {
+                int c = split(rb[s], re[s], depth + 1);
+                BvhNode nd = out_.nodes[me];
+                store_box(nd, s, bounds(rb[s], re[s]));
+                nd.child[s] = c;
+                nd.count[s] = 0;
+                out_.nodes[me] = nd;
+            }
+        }
+        return me;
+    }
+
+    std::vector<Item> &it_;
+    Bvh &out_;
+};
+
+}  // namespace
+
+void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_tri, std::vector<int32_t> &octree_sph_key)
+{
+    out = Accel();
+    octree_tri.assign(d.tri, d.tri + d.n_tri_slots);
+    octree_sph_key.assign(static_cast<size_t>(d.n_sph_slots), 0);
+
+    // Tie-break key of a primitive: its first position in the reference's visiting order
+    // (nodes in depth-first pre-order; within a node triangles, then spheres).
+    std::vector<int32_t> first_key(static_cast<size_t>(d.n_prims), std::numeric_limits<int32_t>::max());
+    std::vector<int32_t> first_tri_slot(static_cast<size_t>(d.n_prims), -1), first_sph_slot(static_cast<size_t>(d.n_prims), -1);
+    int32_t rank = 0;
+    for (int32_t n = 0; n < d.n_nodes; ++n) {
+        const rt_node &nd = d.nodes[n];
+        for (int32_t s = nd.tri_begin; s < nd.tri_begin + nd.tri_count; ++s, ++rank) {
+            int32_t p = d.tri[s].prim;
+            if (first_key[p] > rank) { first_key[p] = rank; first_tri_slot[p] = s; }
+        }
+        for (int32_t s = nd.sph_begin; s < nd.sph_begin + nd.sph_count; ++s, ++rank) {
+            int32_t p = static_cast<int32_t>(d.sph_prim[s] & ~RT_SPH_TRANSPARENT);
+            if (first_key[p] > rank) { first_key[p] = rank; first_sph_slot[p] = s; }
+        }
+    }
+    for (auto &r : octree_tri) {
+        r._pad0 = first_key[r.prim];
+        r._pad1[0] = r.ab[1] * r.ac[2] - r.ac[1] * r.ab[2];
+        r._pad1[1] = 0;
+    }
+    for (int32_t s = 0; s < d.n_sph_slots; ++s) octree_sph_key[s] = first_key[d.sph_prim[s] & ~RT_SPH_TRANSPARENT];
+
+    // one item per distinct primitive that is resident somewhere in the octree
+    std::vector<Item> tri_items, sph_items;
+    for (int32_t p = 0; p < d.n_prims; ++p) {
+        if (first_tri_slot[p] >= 0) {
+            const rt_tri_rec &r = d.tri[first_tri_slot[p]];
+            Item it;
+            for (int k = 0; k < 3; ++k) {
+                const double v0 = r.v0[k], v1 = r.v0[k] - r.ab[k], v2 = r.v0[k] - r.ac[k];
+                it.lo[k] = std::min({v0, v1, v2});
+                it.hi[k] = std::max({v0, v1, v2});
+                it.c[k] = 0.5 * (it.lo[k] + it.hi[k]);
+            }
+            it.src = first_tri_slot[p];
+            tri_items.push_back(it);
+        } else if (first_sph_slot[p] >= 0) {
+            const rt_sph_rec &r = d.sph[first_sph_slot[p]];
+            Item it;
+            for (int k = 0; k < 3; ++k) { it.lo[k] = r.center[k] - r.radius; it.hi[k] = r.center[k] + r.radius; it.c[k] = r.center[k]; }
+            it.src = first_sph_slot[p];
+            sph_items.push_back(it);
+        }
+    }
+    Builder(tri_items, out.tri_bvh).run();
+    Builder(sph_items, out.sph_bvh).run();
+    out.tri.reserve(tri_items.size());
+    for (const Item &it : tri_items) out.tri.push_back(octree_tri[it.src]);
+    out.sph.reserve(sph_items.size());
+    for (const Item &it : sph_items) {
+        out.sph.push_back(d.sph[it.src]);
+        out.sph_prim.push_back(d.sph_prim[it.src]);
+        out.sph_key.push_back(octree_sph_key[it.src]);
+    }
+    out.usable = out.tri_bvh.max_depth <= 32 && out.sph_bvh.max_depth <= 32;
+}
+
+}  // namespace accel

@@ -1,0 +1,46 @@
+// Internal acceleration structure derived from the flattened octree at upload time.
+//
+// The octree arrays of rt_scene_desc define WHAT a ray query returns (the reference's
+// traversal).  For scenes where that result provably equals "nearest / any intersection
+// over all primitives" (see accel_build.cpp), the device answers the same query through
+// two bounding-volume hierarchies (one over triangles, one over spheres) whose leaves
+// hold the same primitive records, so far fewer exact primitive tests are evaluated.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/raytracer_amd.h"
+
+namespace accel {
+
+// Two children per node, each with its own box; 128 bytes.
+struct BvhNode {
+    double lo[2][3];
+    double hi[2][3];
+    int32_t child[2];   // count == 0: index of the child node; count > 0: first leaf record
+    int32_t count[2];   // number of leaf records (0 for an inner child)
+    int32_t _pad[4];
+};
+static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
+
+struct Bvh {
+    std::vector<BvhNode> nodes;   // node 0 is the root; empty when there are no primitives
+    int32_t max_depth = 0;
+    // root box (for the single-leaf / empty cases the root node still has two child slots)
+};
+
+struct Accel {
+    Bvh tri_bvh, sph_bvh;
+    std::vector<rt_tri_rec> tri;        // leaf-ordered; _pad0 = tie-break key, _pad1[0] = ab.y*ac.z - ac.y*ab.z
+    std::vector<rt_sph_rec> sph;        // leaf-ordered
+    std::vector<uint32_t> sph_prim;     // primitive id | RT_SPH_TRANSPARENT
+    std::vector<int32_t> sph_key;       // tie-break key
+    bool usable = false;                // false: keep to the octree walk
+};
+
+// Also fills the per-slot helper fields of `octree_tri` (copy of desc.tri): key and the
+// ray-independent minor.  `octree_sph_key` receives one key per octree sphere slot.
+void build(const rt_scene_desc &desc, Accel &out, std::vector<rt_tri_rec> &octree_tri,
+           std::vector<int32_t> &octree_sph_key);
+
+}  // namespace accel

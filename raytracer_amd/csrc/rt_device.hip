@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "../../include/raytracer_amd.h"
+#include "accel_build.hpp"
 
 // ------------------------------------------------------------------ errors
 namespace {
@@ -85,6 +86,14 @@ struct DevScene {
     const rt_light *lights;
     int32_t n_nodes, n_lights;
     double bg[3];
+    // derived hierarchies (accel_build.hpp); leaf records share the layout of the octree slots
+    const accel::BvhNode *tri_nodes;
+    const rt_tri_rec *btri;
+    const accel::BvhNode *sph_nodes;
+    const rt_sph_rec *bsph;
+    const uint32_t *bsph_prim;
+    const int32_t *bsph_key;
+    int32_t n_tri_nodes, n_sph_nodes;
 };
 
 struct FrameParams {
@@ -95,7 +104,7 @@ struct FrameParams {
     uint32_t flags, seed;
     int32_t band_rows, n_parts, part, local_rows;
     int32_t tiles_x;             // 8x8 sub-sample tiles per row of tiles
-    int32_t cull_closest, cull_shadow, exact_shadow_order;
+    int32_t cull_closest, cull_shadow;
     double *accum;               // local_rows*resx*3
     int32_t *hit_id;             // local_rows*resx or null
     uint8_t *lc_mask;            // local_rows*resx or null
@@ -177,6 +186,44 @@ DEV double tri_test(const rt_tri_rec *tr, d3 o, d3 d, double minT, double maxT, 
     return t;
 }
 
+// The same test with its rejections decided before any division.  The four determinants are
+// built from shared 2x2 minors in the reference's association, so detA, X, Y, Z are bit-identical
+// to det3(); a miss is declared early only when the quotient the reference would form is beyond
+// its threshold by more than the rounding of one division (factor 1 +- 2^-40), otherwise the exact
+// sequence above runs.  `tcut` <= maxT: a hit farther than tcut may be reported as maxT (it
+// cannot replace the current nearest hit, and for shadow queries tcut == maxT).
+DEV double tri_test_fast(const rt_tri_rec *tr, d3 o, d3 d, double minT, double maxT, double tcut)
+{
+    const d3 v0 = ld3(tr->v0), ab = ld3(tr->ab), ac = ld3(tr->ac);
+    const double m3 = tr->_pad1[0];                 // ab.y*ac.z - ac.y*ab.z, filled at upload
+    const d3 ae = sub3(v0, o);
+    const double m1 = ac.y * d.z - d.y * ac.z;
+    const double m2 = d.y * ab.z - ab.y * d.z;
+    const double detA = ab.x * m1 + ac.x * m2 + d.x * m3;
+    const double m4 = d.y * ae.z - ae.y * d.z;
+    const double m5 = ae.y * ac.z - ac.y * ae.z;
+    const double m6 = ab.y * ae.z - ae.y * ab.z;
+    const double X = ae.x * m1 + ac.x * m4 + d.x * m5;          // det3(ae, ac, d)
+    const double Y = ab.x * (-m4) + ae.x * m2 + d.x * m6;       // det3(ab, ae, d)
+    const double Z = ab.x * (-m5) + ac.x * (-m6) + ae.x * m3;   // det3(ab, ac, ae)
+    const double ad = fabs(detA);
+    if (ad > 1e-150 && ad < 1e150) {
+        const double sg = detA < 0 ? -1.0 : 1.0;
+        const double sX = sg * X, sY = sg * Y, sZ = sg * Z;
+        const double up = ad * (1.0 + 0x1p-40);
+        bool miss = (sX < -1e-150) || (sX > up) || (sY < -1e-150) || (sX + sY > ad * (1.0 + 0x1p-30)) ||
+                    (sZ < (minT * ad) * (1.0 - 0x1p-40)) || (sZ > (tcut * ad) * (1.0 + 0x1p-40));
+        if (miss && fabs(X) < 1e150 && fabs(Y) < 1e150 && fabs(Z) < 1e150) return maxT;
+    }
+    double alpha = X / detA;
+    if (alpha < 0 || alpha > 1) return maxT;
+    double beta = Y / detA;
+    if (beta < 0 || beta > 1 - alpha) return maxT;
+    double t = Z / detA;
+    if (t < minT || t > maxT) return maxT;
+    return t;
+}
+
 // Sphere::intersect (Sphere.h:35-77) without the hit-record update; returns t or maxT.
 DEV double sph_test(const rt_sph_rec *sp, d3 o, d3 d, double d2, double minT, double maxT)
 {
@@ -226,8 +273,7 @@ DEV void trace_closest(const DevScene &S, d3 o, d3 d, bool cull, double &best_t,
         }
         if (tcur >= tend && scur >= send) break;
         while (tcur < tend) {
-            double al, be;
-            double t = tri_test(&S.tri[tcur], o, d, minT, maxT, &al, &be);
+            double t = tri_test_fast(&S.tri[tcur], o, d, minT, maxT, best_t);
             if (t < best_t) { best_t = t; best = tcur; }
             ++tcur;
         }
@@ -267,8 +313,7 @@ DEV bool trace_shadow(const DevScene &S, d3 o, d3 d, int parent, double maxT, bo
         for (int s = tb; s < te; ++s) {
             const rt_tri_rec *tr = &S.tri[s];
             if (tr->prim == parent) continue;
-            double al, be;
-            double t = tri_test(tr, o, d, minT, maxT, &al, &be);
+            double t = tri_test_fast(tr, o, d, minT, maxT, maxT);
             if (t < maxT) {   // a triangle always ends the query (Octree.h:1241-1251)
                 if (t > furthest) *closest = tr->prim;
                 *only_transparent = false;
@@ -291,6 +336,145 @@ DEV bool trace_shadow(const DevScene &S, d3 o, d3 d, int parent, double maxT, bo
         idx = idx + 1;
     }
     return seen;
+}
+
+// ------------------------------------------------------------------ hierarchy traversal
+// Stack of pending nodes in LDS: entry k of a lane lives at stack[k * 256 + lane-in-block], so a
+// wave's push or pop touches 64 consecutive banks.
+#define BVH_STACK 32
+
+struct RayBox {
+    d3 o, inv;
+};
+DEV RayBox make_raybox(d3 o, d3 d)
+{
+    RayBox r;
+    r.o = o;
+    // an exactly axis-parallel ray is nudged by 1e-150 for the box test only (0 * inf would be NaN)
+    r.inv.x = 1.0 / (fabs(d.x) < 1e-150 ? (d.x < 0 ? -1e-150 : 1e-150) : d.x);
+    r.inv.y = 1.0 / (fabs(d.y) < 1e-150 ? (d.y < 0 ? -1e-150 : 1e-150) : d.y);
+    r.inv.z = 1.0 / (fabs(d.z) < 1e-150 ? (d.z < 0 ? -1e-150 : 1e-150) : d.z);
+    return r;
+}
+// Slab test against child `s` of a node; returns entry distance or a value > limit when missed.
+DEV double box_entry(const accel::BvhNode *n, int s, const RayBox &r, double limit)
+{
+    double ax = (n->lo[s][0] - r.o.x) * r.inv.x, bx = (n->hi[s][0] - r.o.x) * r.inv.x;
+    double ay = (n->lo[s][1] - r.o.y) * r.inv.y, by = (n->hi[s][1] - r.o.y) * r.inv.y;
+    double az = (n->lo[s][2] - r.o.z) * r.inv.z, bz = (n->hi[s][2] - r.o.z) * r.inv.z;
+    double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), 0.0));
+    double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), limit));
+    return (tn <= tf) ? tn : 1e300;
+}
+
+struct Best {
+    double t;
+    int key;      // tie-break: position in the reference's visiting order
+    int slot;     // record index | SLOT_SPHERE
+};
+
+// Nearest hit over one hierarchy.  TRI selects the leaf record type.
+template <bool TRI>
+DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox &rb, Best &best, int *stack)
+{
+    const double minT = .01, maxT = 10000000000.0;
+    const accel::BvhNode *nodes = TRI ? S.tri_nodes : S.sph_nodes;
+    if ((TRI ? S.n_tri_nodes : S.n_sph_nodes) == 0) return;
+    int cur = 0, sp = 0;
+    while (true) {
+        const accel::BvhNode *n = &nodes[cur];
+        const double limit = best.t * (1.0 + 1e-12) + 1e-12;
+        double e0 = (n->child[0] >= 0) ? box_entry(n, 0, rb, limit) : 1e300;
+        double e1 = (n->child[1] >= 0) ? box_entry(n, 1, rb, limit) : 1e300;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const double e = s ? e1 : e0;
+            const int cnt = n->count[s];
+            if (e < 1e300 && cnt > 0) {
+                const int b = n->child[s];
+                for (int k = b; k < b + cnt; ++k) {
+                    double t;
+                    int key;
+                    if (TRI) { t = tri_test_fast(&S.btri[k], o, d, minT, maxT, best.t); key = S.btri[k]._pad0; }
+                    else { t = sph_test(&S.bsph[k], o, d, d2, minT, maxT); key = S.bsph_key[k]; }
+                    if (t < best.t || (t == best.t && t < maxT && key < best.key)) {
+                        best.t = t; best.key = key; best.slot = TRI ? k : (k | SLOT_SPHERE);
+                    }
+                }
+                if (s) e1 = 1e300; else e0 = 1e300;
+            }
+        }
+        const bool h0 = e0 < 1e300, h1 = e1 < 1e300;
+        if (h0 && h1) {
+            const bool near0 = e0 <= e1;
+            stack[sp * 256] = near0 ? n->child[1] : n->child[0];
+            ++sp;
+            cur = near0 ? n->child[0] : n->child[1];
+        } else if (h0) cur = n->child[0];
+        else if (h1) cur = n->child[1];
+        else {
+            if (sp == 0) break;
+            --sp;
+            cur = stack[sp * 256];
+        }
+    }
+}
+
+// Any hit in (minT, maxT) by a primitive other than `parent`.
+template <bool TRI>
+DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox &rb, int parent, double maxT, int *stack)
+{
+    const double minT = .01;
+    const accel::BvhNode *nodes = TRI ? S.tri_nodes : S.sph_nodes;
+    if ((TRI ? S.n_tri_nodes : S.n_sph_nodes) == 0) return false;
+    const double limit = maxT * (1.0 + 1e-12) + 1e-12;
+    int cur = 0, sp = 0;
+    while (true) {
+        const accel::BvhNode *n = &nodes[cur];
+        double e0 = (n->child[0] >= 0) ? box_entry(n, 0, rb, limit) : 1e300;
+        double e1 = (n->child[1] >= 0) ? box_entry(n, 1, rb, limit) : 1e300;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const double e = s ? e1 : e0;
+            const int cnt = n->count[s];
+            if (e < 1e300 && cnt > 0) {
+                const int b = n->child[s];
+                for (int k = b; k < b + cnt; ++k) {
+                    double t;
+                    if (TRI) {
+                        if (S.btri[k].prim == parent) continue;
+                        t = tri_test_fast(&S.btri[k], o, d, minT, maxT, maxT);
+                    } else {
+                        if ((int)(S.bsph_prim[k] & ~RT_SPH_TRANSPARENT) == parent) continue;
+                        t = sph_test(&S.bsph[k], o, d, d2, minT, maxT);
+                    }
+                    if (t < maxT) return true;
+                }
+                if (s) e1 = 1e300; else e0 = 1e300;
+            }
+        }
+        const bool h0 = e0 < 1e300, h1 = e1 < 1e300;
+        if (h0 && h1) {
+            stack[sp * 256] = n->child[1];
+            ++sp;
+            cur = n->child[0];
+        } else if (h0) cur = n->child[0];
+        else if (h1) cur = n->child[1];
+        else {
+            if (sp == 0) break;
+            --sp;
+            cur = stack[sp * 256];
+        }
+    }
+    return false;
+}
+
+// The root node's own test (Octree.h:1006, 1210): when it fails the reference sees nothing at all.
+DEV bool root_gate(const DevScene &S, d3 o, d3 d, double d2, double sentinel)
+{
+    double entry;
+    double ret = bound_test(&S.nodes[0], o, d, d2, .01, sentinel, &entry);
+    return !(ret >= sentinel);
 }
 
 // Counter-based stand-in for the reference's shared rand() % 1000 / 1000 (Camera.h:99-103).
@@ -342,9 +526,11 @@ DEV void accum_add(double *accum, uint32_t pixel, double w, d3 c)
 }
 
 // ------------------------------------------------------------------ kernels
-template <bool PRIMARY>
+template <bool PRIMARY, bool BVH>
 __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
 {
+    __shared__ int s_stack[BVH ? BVH_STACK * 256 : 1];
+    int *stack = &s_stack[BVH ? threadIdx.x : 0];
     const int lane = (int)(threadIdx.x & 63);
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
@@ -425,7 +611,25 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
         }
         double best_t = 0;
         int best = -1;
-        if (active) trace_closest(P.S, o, d, cull, best_t, best);
+        if (active) {
+            if (BVH) {
+                const double d2 = dot3(d, d);
+                Best bst;
+                bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1;
+                if (root_gate(P.S, o, d, d2, 10000000000.0)) {
+                    const RayBox rb = make_raybox(o, d);
+                    bvh_closest<true>(P.S, o, d, d2, rb, bst, stack);
+                    bvh_closest<false>(P.S, o, d, d2, rb, bst, stack);
+                }
+                best_t = bst.t;
+                best = bst.slot;
+            } else {
+                trace_closest(P.S, o, d, cull, best_t, best);
+            }
+        }
+        const rt_tri_rec *tri_arr = BVH ? P.S.btri : P.S.tri;
+        const rt_sph_rec *sph_arr = BVH ? P.S.bsph : P.S.sph;
+        const uint32_t *sph_prim_arr = BVH ? P.S.bsph_prim : P.S.sph_prim;
 
         const bool first = (meta & 0x100u) != 0;
         const int L = (int)(meta & 0xffu);
@@ -442,11 +646,11 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
             d3 nraw;
             if (best & SLOT_SPHERE) {
                 const int s = best & ~SLOT_SPHERE;
-                prim = (int)(P.S.sph_prim[s] & ~RT_SPH_TRANSPARENT);
-                const rt_sph_rec *sp = &P.S.sph[s];
+                prim = (int)(sph_prim_arr[s] & ~RT_SPH_TRANSPARENT);
+                const rt_sph_rec *sp = &sph_arr[s];
                 nraw = div3(sub3(add3(o, scale3(best_t, d)), ld3(sp->center)), sp->radius);
             } else {
-                const rt_tri_rec *tr = &P.S.tri[best];
+                const rt_tri_rec *tr = &tri_arr[best];
                 prim = tr->prim;
                 const double *pn = &P.S.prim_normals[(size_t)prim * 12];
                 nraw = ld3(pn);
@@ -529,8 +733,11 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
     }
 }
 
+template <bool BVH>
 __global__ __launch_bounds__(256) void k_shadow(FrameParams P, QueueSet Q)
 {
+    __shared__ int s_stack[BVH ? BVH_STACK * 256 : 1];
+    int *stack = &s_stack[BVH ? threadIdx.x : 0];
     const uint32_t n_hits = min(Q.counts[8 + Q.generation], Q.hit_capacity);
     const long long total = (long long)n_hits * P.S.n_lights;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -545,9 +752,21 @@ __global__ __launch_bounds__(256) void k_shadow(FrameParams P, QueueSet Q)
         const d3 toL = sub3(lpos, Pt);
         const d3 rd = unit3(toL);
         const double maxT = norm3(toL) - .01;
-        bool only;
-        int closest;
-        bool occluded = trace_shadow(P.S, Pt, rd, hr->prim, maxT, cull, &only, &closest);
+        bool only = false;
+        int closest = -1;
+        bool occluded;
+        if (BVH) {
+            // no transparent sphere in the scene: "occluded" is "any hit", and never "only transparent"
+            const double d2 = dot3(rd, rd);
+            occluded = false;
+            if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
+                const RayBox rb = make_raybox(Pt, rd);
+                occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack) ||
+                           bvh_any<false>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack);
+            }
+        } else {
+            occluded = trace_shadow(P.S, Pt, rd, hr->prim, maxT, cull, &only, &closest);
+        }
         double kfac = .999999;
         if (occluded && only) {
             // shadowed by transparent spheres only: the reference consults its light camera here
@@ -617,6 +836,7 @@ struct rt_ctx {
     bool any_transparent = false;          // any material with T > 0
     bool any_transparent_sphere = false;
     bool spheres_inside_root = true;       // every sphere lies inside the root cube
+    bool accel_usable = false;             // hierarchies built and shallow enough for the LDS stack
     int32_t lightcam_samples = 150;
     // frame resources (grow-only)
     double *accum = nullptr; size_t accum_values = 0;
@@ -761,7 +981,20 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     free_scene(ctx);
     DevScene D{};
     if ((rc = upload(ctx, s->nodes, (size_t)s->n_nodes, &D.nodes)) != RT_OK) return rc;
-    if ((rc = upload(ctx, s->tri, (size_t)s->n_tri_slots, &D.tri)) != RT_OK) return rc;
+    accel::Accel acc;
+    std::vector<rt_tri_rec> octree_tri;
+    std::vector<int32_t> octree_sph_key;
+    accel::build(*s, acc, octree_tri, octree_sph_key);
+    if ((rc = upload(ctx, octree_tri.data(), octree_tri.size(), &D.tri)) != RT_OK) return rc;
+    if ((rc = upload(ctx, acc.tri_bvh.nodes.data(), acc.tri_bvh.nodes.size(), &D.tri_nodes)) != RT_OK) return rc;
+    if ((rc = upload(ctx, acc.sph_bvh.nodes.data(), acc.sph_bvh.nodes.size(), &D.sph_nodes)) != RT_OK) return rc;
+    if ((rc = upload(ctx, acc.tri.data(), acc.tri.size(), &D.btri)) != RT_OK) return rc;
+    if ((rc = upload(ctx, acc.sph.data(), acc.sph.size(), &D.bsph)) != RT_OK) return rc;
+    if ((rc = upload(ctx, acc.sph_prim.data(), acc.sph_prim.size(), &D.bsph_prim)) != RT_OK) return rc;
+    if ((rc = upload(ctx, acc.sph_key.data(), acc.sph_key.size(), &D.bsph_key)) != RT_OK) return rc;
+    D.n_tri_nodes = (int32_t)acc.tri_bvh.nodes.size();
+    D.n_sph_nodes = (int32_t)acc.sph_bvh.nodes.size();
+    ctx->accel_usable = acc.usable;
     if ((rc = upload(ctx, s->sph, (size_t)s->n_sph_slots, &D.sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->sph_prim, (size_t)s->n_sph_slots, &D.sph_prim)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->prim_flags, (size_t)s->n_prims, &D.prim_flags)) != RT_OK) return rc;
@@ -871,6 +1104,11 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const bool may_cull = !(o->flags & RT_FLAG_NO_CULL) && ctx->spheres_inside_root;
     P.cull_closest = may_cull ? 1 : 0;
     P.cull_shadow = (may_cull && !ctx->any_transparent_sphere) ? 1 : 0;
+    // The hierarchies answer "nearest / any hit over all primitives"; that equals the reference's
+    // walk when every sphere is inside the root cube, and for shadow queries only when no
+    // transparent sphere exists (checkOccluded3 is then order-free).
+    const bool bvh_closest_ok = may_cull && ctx->accel_usable;
+    const bool bvh_shadow_ok = bvh_closest_ok && !ctx->any_transparent_sphere;
 
     hipStream_t st = ctx->stream;
     HIP_TRY(hipEventRecord(ctx->ev_begin, st));
@@ -945,9 +1183,11 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 if (g == 0) {
                     long long blocks = (t1 - t0 + 3) / 4;
                     if (blocks > max_blocks) blocks = max_blocks;
-                    hipLaunchKernelGGL(k_closest<true>, dim3((unsigned)blocks), dim3(256), 0, st, P, Q);
+                    if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q);
+                    else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q);
                 } else {
-                    hipLaunchKernelGGL(k_closest<false>, dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
+                    if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<false, true>), dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
+                    else hipLaunchKernelGGL((k_closest<false, false>), dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
                 }
                 if (ev) HIP_TRY(hipEventRecord(ev->second, st));
                 if (P.S.n_lights > 0) {
@@ -955,7 +1195,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     if (timing && !(ev = next_event_pair(ctx->ev_shadow, ctx->ev_shadow_used)))
                         return fail(RT_ERR_DEVICE, "hipEventCreate failed");
                     if (ev) HIP_TRY(hipEventRecord(ev->first, st));
-                    hipLaunchKernelGGL(k_shadow, dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
+                    if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
+                    else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
                     if (ev) HIP_TRY(hipEventRecord(ev->second, st));
                 }
             }
