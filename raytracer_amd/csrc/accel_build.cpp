@@ -105,7 +105,7 @@ private:
     void set_leaf(BvhNode &nd, int side, int b, int e)
     {
         store_box(nd, side, bounds(b, e));
-        nd.child[side] = b;
+        nd.child[side] = -2 - (b * 4 + (e - b - 1));   // leaf code: first record and count-1 in two bits
         nd.count[side] = e - b;
     }
 
@@ -266,7 +266,8 @@ void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_t
         out.sph_prim.push_back(d.sph_prim[it.src]);
         out.sph_key.push_back(octree_sph_key[it.src]);
     }
-    out.usable = out.tri_bvh.max_depth <= 32 && out.sph_bvh.max_depth <= 32;
+    out.usable = out.tri_bvh.max_depth <= 32 && out.sph_bvh.max_depth <= 32 && out.tri.size() < (1u << 28) &&
+                 out.sph.size() < (1u << 28);
 }
 
 }  // namespace accel

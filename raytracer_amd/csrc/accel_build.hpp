@@ -17,8 +17,8 @@ namespace accel {
 struct BvhNode {
     double lo[2][3];
     double hi[2][3];
-    int32_t child[2];   // count == 0: index of the child node; count > 0: first leaf record
-    int32_t count[2];   // number of leaf records (0 for an inner child)
+    int32_t child[2];   // >= 0: index of the child node; -1: no child; else leaf code -2-(first*4+count-1)
+    int32_t count[2];   // number of leaf records (0 for an inner child); informational
     int32_t _pad[4];
 };
 static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");

@@ -103,21 +103,30 @@ struct FrameParams {
     double aperture;
     uint32_t flags, seed;
     int32_t band_rows, n_parts, part, local_rows;
-    int32_t tiles_x;             // 8x8 sub-sample tiles per row of tiles
+    int32_t blocks_x;            // 8x8-pixel blocks per row of blocks (primary sample ordering)
     int32_t cull_closest, cull_shadow;
     double *accum;               // local_rows*resx*3
     int32_t *hit_id;             // local_rows*resx or null
     uint8_t *lc_mask;            // local_rows*resx or null
 };
 
+// Queues are cut into N_SHARDS independent shards (a block pushes into shard blockIdx % N_SHARDS),
+// so that no single counter word serialises the pushes of the whole chip; a consumer walks the
+// shards' 64-ray chunks as one list.
+#define N_SHARDS 64
+#define CNT_RAYS(g) ((g) * N_SHARDS)             // g = 0..6
+#define CNT_HITS(g) ((7 + (g)) * N_SHARDS)       // g = 0..5
+#define CNT_OVERFLOW (13 * N_SHARDS)
+#define CNT_WORDS (13 * N_SHARDS + 16)
+
 struct QueueSet {
     RayRec *rays_in;
     RayRec *rays_out;
     HitRec *hits;
-    uint32_t *counts;            // [0..6] ray counts per generation, [8..13] hit counts per generation, [15] overflow
-    uint32_t ray_capacity, hit_capacity;
+    uint32_t *counts;
+    uint32_t in_shard_cap, out_shard_cap, hit_shard_cap;   // records per shard
     int32_t generation;
-    int64_t tile_begin, tile_end;  // PRIMARY only
+    int64_t chunk_begin, chunk_end;  // PRIMARY only: 64-sample chunks of the primary ordering
 };
 
 // ------------------------------------------------------------------ device math
@@ -373,7 +382,35 @@ struct Best {
     int slot;     // record index | SLOT_SPHERE
 };
 
-// Nearest hit over one hierarchy.  TRI selects the leaf record type.
+// Child codes (accel_build.hpp): >= 0 inner node, BVH_NONE nothing, otherwise a leaf range.
+#define BVH_NONE (-1)
+DEV int leaf_begin(int code) { return (-2 - code) >> 2; }
+DEV int leaf_count(int code) { return ((-2 - code) & 3) + 1; }
+
+// One step down from inner node `cur`: tests both child boxes against [0, limit], pushes the
+// farther hit child and returns the nearer one (or pops when neither is hit).
+DEV int bvh_step(const accel::BvhNode *nodes, int cur, const RayBox &rb, double limit, bool ordered, int *stack, int &sp)
+{
+    const accel::BvhNode *n = &nodes[cur];
+    const int c0 = n->child[0], c1 = n->child[1];
+    const double e0 = (c0 != BVH_NONE) ? box_entry(n, 0, rb, limit) : 1e300;
+    const double e1 = (c1 != BVH_NONE) ? box_entry(n, 1, rb, limit) : 1e300;
+    const bool h0 = e0 < 1e300, h1 = e1 < 1e300;
+    if (h0 && h1) {
+        const bool near0 = !ordered || e0 <= e1;
+        stack[sp * 256] = near0 ? c1 : c0;
+        ++sp;
+        return near0 ? c0 : c1;
+    }
+    if (h0) return c0;
+    if (h1) return c1;
+    if (sp == 0) return BVH_NONE;
+    --sp;
+    return stack[sp * 256];
+}
+
+// Nearest hit over one hierarchy.  TRI selects the leaf record type.  Two phases per round:
+// every lane descends until it holds a leaf (or is done), then the wave tests leaves together.
 template <bool TRI>
 DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox &rb, Best &best, int *stack)
 {
@@ -382,41 +419,21 @@ DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox &rb,
     if ((TRI ? S.n_tri_nodes : S.n_sph_nodes) == 0) return;
     int cur = 0, sp = 0;
     while (true) {
-        const accel::BvhNode *n = &nodes[cur];
-        const double limit = best.t * (1.0 + 1e-12) + 1e-12;
-        double e0 = (n->child[0] >= 0) ? box_entry(n, 0, rb, limit) : 1e300;
-        double e1 = (n->child[1] >= 0) ? box_entry(n, 1, rb, limit) : 1e300;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const double e = s ? e1 : e0;
-            const int cnt = n->count[s];
-            if (e < 1e300 && cnt > 0) {
-                const int b = n->child[s];
-                for (int k = b; k < b + cnt; ++k) {
-                    double t;
-                    int key;
-                    if (TRI) { t = tri_test_fast(&S.btri[k], o, d, minT, maxT, best.t); key = S.btri[k]._pad0; }
-                    else { t = sph_test(&S.bsph[k], o, d, d2, minT, maxT); key = S.bsph_key[k]; }
-                    if (t < best.t || (t == best.t && t < maxT && key < best.key)) {
-                        best.t = t; best.key = key; best.slot = TRI ? k : (k | SLOT_SPHERE);
-                    }
-                }
-                if (s) e1 = 1e300; else e0 = 1e300;
+        while (cur >= 0) cur = bvh_step(nodes, cur, rb, best.t * (1.0 + 1e-12) + 1e-12, true, stack, sp);
+        if (cur == BVH_NONE) break;
+        const int b = leaf_begin(cur), e = b + leaf_count(cur);
+        for (int k = b; k < e; ++k) {
+            double t;
+            int key;
+            if (TRI) { t = tri_test_fast(&S.btri[k], o, d, minT, maxT, best.t); key = S.btri[k]._pad0; }
+            else { t = sph_test(&S.bsph[k], o, d, d2, minT, maxT); key = S.bsph_key[k]; }
+            if (t < best.t || (t == best.t && t < maxT && key < best.key)) {
+                best.t = t; best.key = key; best.slot = TRI ? k : (k | SLOT_SPHERE);
             }
         }
-        const bool h0 = e0 < 1e300, h1 = e1 < 1e300;
-        if (h0 && h1) {
-            const bool near0 = e0 <= e1;
-            stack[sp * 256] = near0 ? n->child[1] : n->child[0];
-            ++sp;
-            cur = near0 ? n->child[0] : n->child[1];
-        } else if (h0) cur = n->child[0];
-        else if (h1) cur = n->child[1];
-        else {
-            if (sp == 0) break;
-            --sp;
-            cur = stack[sp * 256];
-        }
+        if (sp == 0) break;
+        --sp;
+        cur = stack[sp * 256];
     }
 }
 
@@ -430,41 +447,23 @@ DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox &rb, int
     const double limit = maxT * (1.0 + 1e-12) + 1e-12;
     int cur = 0, sp = 0;
     while (true) {
-        const accel::BvhNode *n = &nodes[cur];
-        double e0 = (n->child[0] >= 0) ? box_entry(n, 0, rb, limit) : 1e300;
-        double e1 = (n->child[1] >= 0) ? box_entry(n, 1, rb, limit) : 1e300;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const double e = s ? e1 : e0;
-            const int cnt = n->count[s];
-            if (e < 1e300 && cnt > 0) {
-                const int b = n->child[s];
-                for (int k = b; k < b + cnt; ++k) {
-                    double t;
-                    if (TRI) {
-                        if (S.btri[k].prim == parent) continue;
-                        t = tri_test_fast(&S.btri[k], o, d, minT, maxT, maxT);
-                    } else {
-                        if ((int)(S.bsph_prim[k] & ~RT_SPH_TRANSPARENT) == parent) continue;
-                        t = sph_test(&S.bsph[k], o, d, d2, minT, maxT);
-                    }
-                    if (t < maxT) return true;
-                }
-                if (s) e1 = 1e300; else e0 = 1e300;
+        while (cur >= 0) cur = bvh_step(nodes, cur, rb, limit, false, stack, sp);
+        if (cur == BVH_NONE) break;
+        const int b = leaf_begin(cur), e = b + leaf_count(cur);
+        for (int k = b; k < e; ++k) {
+            double t;
+            if (TRI) {
+                if (S.btri[k].prim == parent) continue;
+                t = tri_test_fast(&S.btri[k], o, d, minT, maxT, maxT);
+            } else {
+                if ((int)(S.bsph_prim[k] & ~RT_SPH_TRANSPARENT) == parent) continue;
+                t = sph_test(&S.bsph[k], o, d, d2, minT, maxT);
             }
+            if (t < maxT) return true;
         }
-        const bool h0 = e0 < 1e300, h1 = e1 < 1e300;
-        if (h0 && h1) {
-            stack[sp * 256] = n->child[1];
-            ++sp;
-            cur = n->child[0];
-        } else if (h0) cur = n->child[0];
-        else if (h1) cur = n->child[1];
-        else {
-            if (sp == 0) break;
-            --sp;
-            cur = stack[sp * 256];
-        }
+        if (sp == 0) break;
+        --sp;
+        cur = stack[sp * 256];
     }
     return false;
 }
@@ -499,30 +498,89 @@ DEV int global_row(const FrameParams &P, int local_row)
     return (band * P.n_parts + P.part) * P.band_rows + within;
 }
 
-// Wave-aggregated queue push: one atomic per wave, lanes take consecutive slots.
-DEV uint32_t wave_reserve(bool want, uint32_t *counter, uint32_t capacity, uint32_t *overflow, bool *ok)
+// Wave-aggregated queue push into this block's shard: one atomic per wave, lanes take
+// consecutive slots.  Returns the record index in the whole queue.
+DEV uint32_t wave_reserve(bool want, uint32_t *shard_counters, uint32_t shard_cap, uint32_t *overflow, bool *ok)
 {
+    const uint32_t shard = blockIdx.x & (N_SHARDS - 1);
     unsigned long long mask = __ballot(want);
     uint32_t n = (uint32_t)__popcll(mask);
     uint32_t base = 0;
     if (n) {
         int leader = __ffsll((long long)mask) - 1;
         int lane = (int)(threadIdx.x & 63);
-        if (lane == leader) base = atomicAdd(counter, n);
+        if (lane == leader) base = atomicAdd(&shard_counters[shard], n);
         base = (uint32_t)__shfl((int)base, leader);
     }
     uint32_t rank = (uint32_t)__popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
     uint32_t slot = base + rank;
-    *ok = want && slot < capacity;
-    if (want && slot >= capacity) *overflow = 1u;
-    return slot;
+    *ok = want && slot < shard_cap;
+    if (want && slot >= shard_cap) *overflow = 1u;
+    return shard * shard_cap + slot;
 }
 
-DEV void accum_add(double *accum, uint32_t pixel, double w, d3 c)
+// View of a sharded queue as one list of 64-item chunks.  Lane l keeps shard l's item count and
+// the index of its first chunk; chunk c belongs to the last shard whose first chunk is <= c.
+struct ShardMap {
+    uint32_t items;      // this lane's shard: number of items
+    uint32_t first;      // this lane's shard: first chunk index
+    uint32_t total;      // chunks in all shards
+};
+DEV ShardMap shard_map(const uint32_t *shard_counters, uint32_t shard_cap, uint32_t items_per_record)
 {
-    unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 0], w * c.x);
-    unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 1], w * c.y);
-    unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 2], w * c.z);
+    const int lane = (int)(threadIdx.x & 63);
+    ShardMap m;
+    uint32_t n = shard_counters[lane];
+    if (n > shard_cap) n = shard_cap;
+    m.items = n * items_per_record;
+    uint32_t chunks = (m.items + 63u) >> 6;
+    uint32_t incl = chunks;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += v;
+    }
+    m.first = incl - chunks;
+    m.total = (uint32_t)__shfl((int)incl, 63);
+    return m;
+}
+// For chunk c (same in all lanes): shard, and this lane's item index inside the shard (or -1).
+DEV int shard_locate(const ShardMap &m, uint32_t c, int *shard_out)
+{
+    const unsigned long long le = __ballot(m.first <= c && m.items > 0);
+    const int shard = 63 - __clzll((long long)le);
+    const uint32_t first = (uint32_t)__shfl((int)m.first, shard);
+    const uint32_t items = (uint32_t)__shfl((int)m.items, shard);
+    const uint32_t idx = (c - first) * 64u + (threadIdx.x & 63);
+    *shard_out = shard;
+    return idx < items ? (int)idx : -1;
+}
+
+// Adds w*c to a pixel.  Lanes that hold the same pixel in a contiguous run of lanes are summed
+// first and the run's first lane issues the (memory-side) FP64 atomics.  `in_queue` lanes take
+// part in runs even when they contribute nothing (`valid` false), so a shadowed light does not
+// split the run of its hit.
+DEV void accum_add_runs(double *accum, bool in_queue, bool valid, uint32_t pixel, double w, d3 c)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t key = in_queue ? pixel : 0xFFFFFFFFu;
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    const bool head = (lane == 0) || prev != key;
+    // run id = number of run heads at or before this lane: equal ids <=> same contiguous run
+    const unsigned long long heads = __ballot(head);
+    const int run = __popcll(heads & ((2ull << lane) - 1ull));
+    double vx = valid ? w * c.x : 0.0, vy = valid ? w * c.y : 0.0, vz = valid ? w * c.z : 0.0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int orun = __shfl_down(run, off);
+        const double ox = __shfl_down(vx, off), oy = __shfl_down(vy, off), oz = __shfl_down(vz, off);
+        if (lane + off < 64 && orun == run) { vx += ox; vy += oy; vz += oz; }
+    }
+    if (in_queue && head && (vx != 0.0 || vy != 0.0 || vz != 0.0)) {
+        unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 0], vx);
+        unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 1], vy);
+        unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 2], vz);
+    }
 }
 
 // ------------------------------------------------------------------ kernels
@@ -534,8 +592,10 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
     const int lane = (int)(threadIdx.x & 63);
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
-    const uint32_t in_count = PRIMARY ? 0u : min(Q.counts[Q.generation], Q.ray_capacity);
-    const long long n_chunks = PRIMARY ? (Q.tile_end - Q.tile_begin) : (((long long)in_count + 63) >> 6);
+    ShardMap smap;
+    smap.items = smap.first = smap.total = 0;
+    if (!PRIMARY) smap = shard_map(&Q.counts[CNT_RAYS(Q.generation)], Q.in_shard_cap, 1u);
+    const long long n_chunks = PRIMARY ? (Q.chunk_end - Q.chunk_begin) : (long long)smap.total;
     const bool cull = P.cull_closest != 0;
 
     for (long long chunk = wave; chunk < n_chunks; chunk += n_waves) {
@@ -545,14 +605,19 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
         uint32_t pixel = 0, meta = 5u | 0x100u;
         bool first_sample = false;
         if (PRIMARY) {
-            // 8x8 tile of the sub-sample grid (resx*N wide, local_rows*N high)
-            const long long tile = Q.tile_begin + chunk;
-            const int ty = (int)(tile / P.tiles_x), tx = (int)(tile - (long long)ty * P.tiles_x);
-            const int sx = tx * 8 + (lane & 7), sy = ty * 8 + (lane >> 3);
+            // Primary ordering: pixels in 8x8 blocks (row-major inside a block), the N*N samples of a
+            // pixel in consecutive positions; a wave takes 64 consecutive positions.
             const int N = P.N;
-            active = sx < P.cam.resx * N && sy < P.local_rows * N;
-            const int j = sx / N, sj = sx - j * N;
-            const int lrow = sy / N, si = sy - lrow * N;
+            const long long pos = (Q.chunk_begin + chunk) * 64 + lane;
+            const int spp = N * N;
+            const long long pseq = pos / spp;
+            const int smp = (int)(pos - pseq * spp);
+            const long long blk = pseq >> 6;
+            const int within = (int)(pseq & 63);
+            const int by = (int)(blk / P.blocks_x), bx = (int)(blk - (long long)by * P.blocks_x);
+            const int j = bx * 8 + (within & 7), lrow = by * 8 + (within >> 3);
+            const int si = smp / N, sj = smp - si * N;
+            active = j < P.cam.resx && lrow < P.local_rows;
             const int i = global_row(P, lrow);
             pixel = (uint32_t)lrow * (uint32_t)P.cam.resx + (uint32_t)j;
             first_sample = (si == 0 && sj == 0);
@@ -594,9 +659,10 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
                 d = unit3(sub3(focus, o));
             }
         } else {
-            const long long idx = chunk * 64 + lane;
-            active = idx < (long long)in_count;
-            const RayRec *rr = &Q.rays_in[active ? idx : 0];
+            int shard;
+            const int local = shard_locate(smap, (uint32_t)chunk, &shard);
+            active = local >= 0;
+            const RayRec *rr = &Q.rays_in[active ? (size_t)shard * Q.in_shard_cap + (uint32_t)local : 0];
             o = ld3(rr->o);
             d = ld3(rr->d);
             A = rr->A;
@@ -605,10 +671,6 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
             meta = rr->meta;
         }
 
-        if (PRIMARY) {   // generation-0 ray count (queued generations are counted by their pushes)
-            const unsigned long long am = __ballot(active);
-            if (lane == 0 && am) atomicAdd(&Q.counts[0], (uint32_t)__popcll(am));
-        }
         double best_t = 0;
         int best = -1;
         if (active) {
@@ -635,7 +697,7 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
         const int L = (int)(meta & 0xffu);
         const double wloc = first ? A : A * coef;
         bool hit = active && best >= 0;
-        if (active && !hit) accum_add(P.accum, pixel, wloc, ld3(P.S.bg));
+        accum_add_runs(P.accum, active, active && !hit, pixel, wloc, ld3(P.S.bg));
 
         // hit record (Solid.h:110-125)
         d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0), refl = mk3(0, 0, 0);
@@ -672,7 +734,7 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
         {
             bool ok;
             bool want = hit && P.S.n_lights > 0;
-            uint32_t slot = wave_reserve(want, &Q.counts[8 + Q.generation], Q.hit_capacity, &Q.counts[15], &ok);
+            uint32_t slot = wave_reserve(want, &Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, &Q.counts[CNT_OVERFLOW], &ok);
             if (ok) {
                 HitRec *h = &Q.hits[slot];
                 h->P[0] = Pt.x; h->P[1] = Pt.y; h->P[2] = Pt.z;
@@ -689,7 +751,7 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
         {
             bool want = spawn && m.T > 0;
             bool ok;
-            uint32_t slot = wave_reserve(want, &Q.counts[Q.generation + 1], Q.ray_capacity, &Q.counts[15], &ok);
+            uint32_t slot = wave_reserve(want, &Q.counts[CNT_RAYS(Q.generation + 1)], Q.out_shard_cap, &Q.counts[CNT_OVERFLOW], &ok);
             if (ok) {
                 double ior = m.ior;
                 d3 nn = n;
@@ -719,7 +781,7 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
             const double coef2 = coef * m.Ks;
             bool want = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
             bool ok;
-            uint32_t slot = wave_reserve(want, &Q.counts[Q.generation + 1], Q.ray_capacity, &Q.counts[15], &ok);
+            uint32_t slot = wave_reserve(want, &Q.counts[CNT_RAYS(Q.generation + 1)], Q.out_shard_cap, &Q.counts[CNT_OVERFLOW], &ok);
             if (ok) {
                 RayRec *r = &Q.rays_out[slot];
                 r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
@@ -738,76 +800,99 @@ __global__ __launch_bounds__(256) void k_shadow(FrameParams P, QueueSet Q)
 {
     __shared__ int s_stack[BVH ? BVH_STACK * 256 : 1];
     int *stack = &s_stack[BVH ? threadIdx.x : 0];
-    const uint32_t n_hits = min(Q.counts[8 + Q.generation], Q.hit_capacity);
-    const long long total = (long long)n_hits * P.S.n_lights;
-    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const uint32_t nl = (uint32_t)P.S.n_lights;
+    // work items are (hit, light) pairs, the lights of one hit in consecutive items
+    const ShardMap smap = shard_map(&Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, nl);
     const bool cull = P.cull_shadow != 0;
-    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
-        const uint32_t h = (uint32_t)(k / P.S.n_lights);
-        const int li = (int)(k - (long long)h * P.S.n_lights);
-        const HitRec *hr = &Q.hits[h];
+    for (long long chunk = wave; chunk < (long long)smap.total; chunk += n_waves) {
+        int shard;
+        const int item = shard_locate(smap, (uint32_t)chunk, &shard);
+        const bool active = item >= 0;
+        const uint32_t h = active ? (uint32_t)item / nl : 0u;
+        const int li = active ? (int)((uint32_t)item - h * nl) : 0;
+        const HitRec *hr = &Q.hits[(size_t)shard * Q.hit_shard_cap + h];
         const rt_light *lt = &P.S.lights[li];
         const d3 Pt = ld3(hr->P);
         const d3 lpos = ld3(lt->pos);
-        const d3 toL = sub3(lpos, Pt);
-        const d3 rd = unit3(toL);
-        const double maxT = norm3(toL) - .01;
-        bool only = false;
-        int closest = -1;
-        bool occluded;
-        if (BVH) {
-            // no transparent sphere in the scene: "occluded" is "any hit", and never "only transparent"
-            const double d2 = dot3(rd, rd);
-            occluded = false;
-            if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
-                const RayBox rb = make_raybox(Pt, rd);
-                occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack) ||
-                           bvh_any<false>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack);
-            }
-        } else {
-            occluded = trace_shadow(P.S, Pt, rd, hr->prim, maxT, cull, &only, &closest);
-        }
-        double kfac = .999999;
-        if (occluded && only) {
-            // shadowed by transparent spheres only: the reference consults its light camera here
-            if (P.lc_mask) P.lc_mask[hr->pixel] = 1;
-        }
-        if (occluded) continue;
-        const rt_material m = P.S.materials[P.S.prim_material[hr->prim]];
-        const d3 normal = unit3(ld3(hr->n));
+        const uint32_t pixel = hr->pixel;
+        bool lit = false;
         d3 local = mk3(0, 0, 0);
-        if (m.Ks > 0) {
-            d3 nn = unit3(normal);
-            d3 v = unit3(sub3(ld3(hr->e), Pt));
-            d3 lDir = unit3(sub3(lpos, Pt));
-            d3 rdir = unit3(add3(neg3(lDir), scale3(2.0 * dot3(lDir, nn), nn)));
-            double a = dot3(rdir, v);
-            double pw = pow((a < 0.0) ? 0.0 : a, m.Shine);
-            double ik = lt->intensity * m.Ks;
-            d3 comp = mk3((ik * lt->color[0]) * pw, (ik * lt->color[1]) * pw, (ik * lt->color[2]) * pw);
-            local = add3(local, scale3(kfac, comp));
+        if (active) {
+            const d3 toL = sub3(lpos, Pt);
+            const d3 rd = unit3(toL);
+            const double maxT = norm3(toL) - .01;
+            bool only = false;
+            int closest = -1;
+            bool occluded;
+            if (BVH) {
+                // no transparent sphere in the scene: "occluded" is "any hit", and never "only transparent"
+                const double d2 = dot3(rd, rd);
+                occluded = false;
+                if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
+                    const RayBox rb = make_raybox(Pt, rd);
+                    occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack) ||
+                               bvh_any<false>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack);
+                }
+            } else {
+                occluded = trace_shadow(P.S, Pt, rd, hr->prim, maxT, cull, &only, &closest);
+            }
+            const double kfac = .999999;
+            if (occluded && only) {
+                // shadowed by transparent spheres only: the reference consults its light camera here
+                if (P.lc_mask) P.lc_mask[pixel] = 1;
+            }
+            lit = !occluded;
+            if (lit) {
+                const rt_material m = P.S.materials[P.S.prim_material[hr->prim]];
+                const d3 normal = unit3(ld3(hr->n));
+                if (m.Ks > 0) {
+                    d3 nn = unit3(normal);
+                    d3 v = unit3(sub3(ld3(hr->e), Pt));
+                    d3 lDir = unit3(sub3(lpos, Pt));
+                    d3 rdir = unit3(add3(neg3(lDir), scale3(2.0 * dot3(lDir, nn), nn)));
+                    double a = dot3(rdir, v);
+                    double pw = pow((a < 0.0) ? 0.0 : a, m.Shine);
+                    double ik = lt->intensity * m.Ks;
+                    d3 comp = mk3((ik * lt->color[0]) * pw, (ik * lt->color[1]) * pw, (ik * lt->color[2]) * pw);
+                    local = add3(local, scale3(kfac, comp));
+                }
+                {
+                    double a = dot3(unit3(sub3(lpos, Pt)), normal);
+                    double dm = (a < 0.0) ? 0.0 : a;
+                    double ik = lt->intensity * m.Kd;
+                    d3 comp = mk3((ik * m.r) * dm, (ik * m.g) * dm, (ik * m.b) * dm);
+                    local = add3(local, scale3(kfac, comp));
+                }
+            }
         }
-        {
-            double a = dot3(unit3(sub3(lpos, Pt)), normal);
-            double dm = (a < 0.0) ? 0.0 : a;
-            double ik = lt->intensity * m.Kd;
-            d3 comp = mk3((ik * m.r) * dm, (ik * m.g) * dm, (ik * m.b) * dm);
-            local = add3(local, scale3(kfac, comp));
-        }
-        accum_add(P.accum, hr->pixel, hr->weight, local);
+        accum_add_runs(P.accum, active, lit, pixel, hr->weight, local);
     }
 }
 
-// totals[0]=closest rays, [1]=shadow rays, [2..7]=rays per generation, [8..13]=hits per generation, [15]=overflow
+// totals[0]=closest rays, [1]=shadow rays, [2..7]=rays per generation (generation 0 is filled in by the
+// host, which knows the number of primary samples), [8..13]=hits per generation, [15]=overflow
 __global__ void k_collect_counts(const uint32_t *counts, unsigned long long *totals, int n_lights)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned long long closest = 0, shadow = 0;
-    for (int g = 0; g < 6; ++g) { closest += counts[g]; totals[2 + g] += counts[g]; }
-    for (int g = 0; g < 6; ++g) { shadow += (unsigned long long)counts[8 + g] * n_lights; totals[8 + g] += counts[8 + g]; }
-    totals[0] += closest;
-    totals[1] += shadow;
-    totals[15] += counts[15];
+    const int lane = (int)threadIdx.x;   // one wave, lane = shard
+    if (blockIdx.x != 0 || lane >= N_SHARDS) return;
+    for (int g = 0; g < 6; ++g) {
+        unsigned long long r = (g == 0) ? 0ull : counts[CNT_RAYS(g) + lane];
+        unsigned long long h = counts[CNT_HITS(g) + lane];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            r += __shfl_down(r, off);
+            h += __shfl_down(h, off);
+        }
+        if (lane == 0) {
+            totals[2 + g] += r;
+            totals[8 + g] += h;
+            totals[0] += r;
+            totals[1] += h * (unsigned long long)n_lights;
+        }
+    }
+    if (lane == 0) totals[15] += counts[CNT_OVERFLOW];
 }
 
 __global__ __launch_bounds__(256) void k_finalize(const double *accum, long long n_values, int spp, double *out_f64,
@@ -840,7 +925,7 @@ struct rt_ctx {
     int32_t lightcam_samples = 150;
     // frame resources (grow-only)
     double *accum = nullptr; size_t accum_values = 0;
-    RayRec *rays[2] = {nullptr, nullptr}; size_t ray_capacity = 0;
+    RayRec *rays[2] = {nullptr, nullptr}; size_t ray_capacity[2] = {0, 0};
     HitRec *hits = nullptr; size_t hit_capacity = 0;
     uint32_t *counts = nullptr;
     unsigned long long *totals = nullptr;
@@ -849,6 +934,7 @@ struct rt_ctx {
     // pending async frame
     bool pending = false;
     uint32_t pending_flags = 0;
+    unsigned long long pending_primaries = 0;
     int pending_batches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_shadow;
     size_t ev_closest_used = 0, ev_shadow_used = 0;
@@ -902,7 +988,7 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&ctx->ev_begin));
     HIP_TRY(hipEventCreate(&ctx->ev_end));
-    HIP_TRY(hipMalloc((void **)&ctx->counts, 16 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->counts, CNT_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->totals, 16 * sizeof(unsigned long long)));
     *out = ctx;
     return RT_OK;
@@ -1100,7 +1186,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     P.n_parts = parts;
     P.part = o->part;
     P.local_rows = local_rows;
-    P.tiles_x = (cam->resx * N + 7) / 8;
+    P.blocks_x = (cam->resx + 7) / 8;
     const bool may_cull = !(o->flags & RT_FLAG_NO_CULL) && ctx->spheres_inside_root;
     P.cull_closest = may_cull ? 1 : 0;
     P.cull_shadow = (may_cull && !ctx->any_transparent_sphere) ? 1 : 0;
@@ -1116,6 +1202,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     ctx->ev_closest_used = ctx->ev_shadow_used = 0;
     ctx->pending_flags = o->flags;
     ctx->pending_batches = 0;
+    ctx->pending_primaries = (unsigned long long)n_pixels * (unsigned long long)(N * N);
 
     if (local_rows > 0) {
         int rc;
@@ -1144,45 +1231,66 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         P.lc_mask = static_cast<uint8_t *>(dev[3]);
         if (dev[3]) HIP_TRY(hipMemsetAsync(dev[3], 0, bytes[3], st));
 
-        const long long tiles_y = ((long long)local_rows * N + 7) / 8;
-        const long long n_tiles = tiles_y * P.tiles_x;
-        // queue sizing: a generation has at most fan^g rays per primary sample
-        const long long fan = ctx->any_transparent ? 32 : 1;
-        long long batch_tiles = ctx->batch_override > 0 ? (ctx->batch_override + 63) / 64
-                                                         : (ctx->any_transparent ? (1ll << 21) / 64 : (1ll << 23) / 64);
-        if (batch_tiles > n_tiles) batch_tiles = n_tiles;
-        if (batch_tiles < 1) batch_tiles = 1;
-        const size_t cap = (size_t)(batch_tiles * 64 * fan);
-        if (cap >= ((size_t)1 << 32) - 64) return fail(RT_ERR_INVALID, "rt_render: batch too large for 32-bit queue indices");
-        size_t have0 = ctx->ray_capacity, have1 = ctx->ray_capacity;
-        if ((rc = ensure(&ctx->rays[0], &have0, cap)) != RT_OK) return rc;
-        if ((rc = ensure(&ctx->rays[1], &have1, cap)) != RT_OK) return rc;
-        ctx->ray_capacity = have0 < have1 ? have0 : have1;
-        if ((rc = ensure(&ctx->hits, &ctx->hit_capacity, cap)) != RT_OK) return rc;
+        // primary ordering: 8x8-pixel blocks, N*N samples per pixel -> (N*N) 64-sample chunks per block
+        const long long blocks_y = ((long long)local_rows + 7) / 8;
+        const long long n_chunks = blocks_y * P.blocks_x * (long long)(N * N);
+        long long batch_chunks = ctx->batch_override > 0 ? (ctx->batch_override + 63) / 64
+                                                          : (ctx->any_transparent ? (1ll << 21) / 64 : (1ll << 23) / 64);
+        if (batch_chunks > n_chunks) batch_chunks = n_chunks;
+        if (batch_chunks < 1) batch_chunks = 1;
+
+        // Shard capacities, generation by generation: what one wave can be handed, times the waves
+        // that feed one shard, times the fan-out of a hit (reflection, plus refraction if any
+        // material is transparent).  These are upper bounds, so a push can never overflow.
+        const int max_blocks = ctx->cu_count * 8;
+        const long long fan_out = ctx->any_transparent ? 2 : 1;
+        long long blocks0 = (batch_chunks + 3) / 4;
+        if (blocks0 > max_blocks) blocks0 = max_blocks;
+        const long long waves_q = (long long)max_blocks * 4, wps_q = ((max_blocks + N_SHARDS - 1) / N_SHARDS) * 4ll;
+        long long hit_cap[6], ray_cap[7];
+        ray_cap[0] = 0;
+        {
+            const long long w0 = blocks0 * 4, wps0 = ((blocks0 + N_SHARDS - 1) / N_SHARDS) * 4;
+            hit_cap[0] = ((batch_chunks + w0 - 1) / w0) * 64 * wps0;
+            ray_cap[1] = hit_cap[0] * fan_out;
+        }
+        for (int g = 1; g < 6; ++g) {
+            const long long c_in = N_SHARDS * ((ray_cap[g] + 63) / 64);
+            hit_cap[g] = ((c_in + waves_q - 1) / waves_q) * 64 * wps_q;
+            ray_cap[g + 1] = hit_cap[g] * fan_out;
+        }
+        long long need_rays[2] = {0, 0}, need_hits = 0;
+        for (int g = 1; g < 6; ++g) if (ray_cap[g] * N_SHARDS > need_rays[g & 1]) need_rays[g & 1] = ray_cap[g] * N_SHARDS;
+        for (int g = 0; g < 6; ++g) if (hit_cap[g] * N_SHARDS > need_hits) need_hits = hit_cap[g] * N_SHARDS;
+        if (need_rays[0] >= (1ll << 32) || need_rays[1] >= (1ll << 32) || need_hits >= (1ll << 32))
+            return fail(RT_ERR_INVALID, "rt_render: batch too large for 32-bit queue indices");
+        if ((rc = ensure(&ctx->rays[0], &ctx->ray_capacity[0], (size_t)(need_rays[0] ? need_rays[0] : 64))) != RT_OK) return rc;
+        if ((rc = ensure(&ctx->rays[1], &ctx->ray_capacity[1], (size_t)(need_rays[1] ? need_rays[1] : 64))) != RT_OK) return rc;
+        if ((rc = ensure(&ctx->hits, &ctx->hit_capacity, (size_t)need_hits)) != RT_OK) return rc;
 
         const bool timing = (o->flags & RT_FLAG_TIMING) != 0;
-        const int max_blocks = ctx->cu_count * 8;
-        for (long long t0 = 0; t0 < n_tiles; t0 += batch_tiles) {
-            const long long t1 = (t0 + batch_tiles < n_tiles) ? t0 + batch_tiles : n_tiles;
-            HIP_TRY(hipMemsetAsync(ctx->counts, 0, 16 * sizeof(uint32_t), st));
+        for (long long t0 = 0; t0 < n_chunks; t0 += batch_chunks) {
+            const long long t1 = (t0 + batch_chunks < n_chunks) ? t0 + batch_chunks : n_chunks;
+            HIP_TRY(hipMemsetAsync(ctx->counts, 0, CNT_WORDS * sizeof(uint32_t), st));
             for (int g = 0; g < 6; ++g) {
                 QueueSet Q{};
                 Q.rays_in = ctx->rays[g & 1];
                 Q.rays_out = ctx->rays[(g + 1) & 1];
                 Q.hits = ctx->hits;
                 Q.counts = ctx->counts;
-                Q.ray_capacity = (uint32_t)cap;
-                Q.hit_capacity = (uint32_t)cap;
+                Q.in_shard_cap = (uint32_t)ray_cap[g];
+                Q.out_shard_cap = (uint32_t)(g < 5 ? ray_cap[g + 1] : 0);
+                Q.hit_shard_cap = (uint32_t)hit_cap[g];
                 Q.generation = g;
-                Q.tile_begin = t0;
-                Q.tile_end = t1;
+                Q.chunk_begin = t0;
+                Q.chunk_end = t1;
                 std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
                 if (timing && !(ev = next_event_pair(ctx->ev_closest, ctx->ev_closest_used)))
                     return fail(RT_ERR_DEVICE, "hipEventCreate failed");
                 if (ev) HIP_TRY(hipEventRecord(ev->first, st));
                 if (g == 0) {
                     long long blocks = (t1 - t0 + 3) / 4;
-                    if (blocks > max_blocks) blocks = max_blocks;
+                    if (blocks > blocks0) blocks = blocks0;
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q);
                 } else {
@@ -1232,6 +1340,8 @@ extern "C" int rt_sync(rt_ctx *ctx, rt_stats *stats)
     HIP_TRY(hipMemcpy(tot, ctx->totals, sizeof tot, hipMemcpyDeviceToHost));
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
+        tot[0] += ctx->pending_primaries;   // generation 0 is counted on the host
+        tot[2] = ctx->pending_primaries;
         stats->closest_rays = tot[0];
         stats->shadow_rays = tot[1];
         for (int g = 0; g < 6; ++g) { stats->rays_per_generation[g] = tot[2 + g]; stats->hits_per_generation[g] = tot[8 + g]; }
