@@ -115,25 +115,17 @@ def main():
     gpu = rt.Renderer(local_rank)
     gpu.upload(scene)
 
+    from raytracer_amd.multi import FrameGather
     band = BAND_ROWS if world > 1 else 0
-    rows = rt.part_rows(cam, band, world, rank)
-    max_rows = max(rt.part_rows(cam, band, world, r) for r in range(world))
     dev = torch.device("cuda", local_rank)
-    local = torch.zeros((max_rows, resx, 3), dtype=torch.uint8, device=dev)
-    frame = gathered = row_index = None
-    if world > 1 and rank == 0:
-        frame = torch.zeros((resy, resx, 3), dtype=torch.uint8, device=dev)
-        gathered = [torch.zeros_like(local) for _ in range(world)]
-        row_index = [torch.from_numpy(rt.part_row_indices(resy, band, world, r)).to(dev) for r in range(world)]
+    fg = FrameGather(resx, resy, band, world, rank, dev, dist)
+    assert fg.local_rows == rt.part_rows(cam, band, world, rank)
 
     def step(flags):
-        st = gpu.render_device(cam, rgb_u8_ptr=local.data_ptr(), num_samples=N, flags=flags, band_rows=band,
+        st = gpu.render_device(cam, rgb_u8_ptr=fg.local.data_ptr(), num_samples=N, flags=flags, band_rows=band,
                                n_parts=world, part=rank)
         if world > 1:
-            dist.gather(local, gathered if rank == 0 else None, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    frame.index_copy_(0, row_index[r], gathered[r][: row_index[r].numel()])
+            fg.gather()
         return st
 
     def fence():

@@ -66,8 +66,8 @@ struct alignas(16) RayRec {      // 80 bytes
 
 struct alignas(16) HitRec {      // 96 bytes
     double P[3];                 // impactPos
-    double n[3];                 // hr.normal (normalised once)
-    double e[3];                 // ray origin (hr.e)
+    double n[3];                 // hr.normal normalised a second time, as computeLocalColor does (Camera.h:382)
+    double v[3];                 // unit vector from the hit point to the ray origin (Solid.h:156)
     double weight;               // factor applied to the local colour
     uint32_t pixel;
     int32_t prim;                // the solid that was hit (never occludes itself)
@@ -471,6 +471,15 @@ DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox &rb, int
 // The root node's own test (Octree.h:1006, 1210): when it fails the reference sees nothing at all.
 DEV bool root_gate(const DevScene &S, d3 o, d3 d, double d2, double sentinel)
 {
+    // Origin at least a little inside the root sphere and |d| near 1: the far root is then
+    // > 0.86*sqrt(4*d2*|C|) > 1, far above minT and far below the sentinel, so the test passes
+    // whatever the last bits of the square root and the divisions are.
+    {
+        const rt_node *nd = &S.nodes[0];
+        const d3 emp = sub3(o, ld3(nd->center));
+        const double C = dot3(emp, emp) - nd->radius * nd->radius;
+        if (C < -1.0 && C > -1e6 && d2 > 0.5 && d2 < 2.0) return true;
+    }
     double entry;
     double ret = bound_test(&S.nodes[0], o, d, d2, .01, sentinel, &entry);
     return !(ret >= sentinel);
@@ -738,8 +747,10 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
             if (ok) {
                 HitRec *h = &Q.hits[slot];
                 h->P[0] = Pt.x; h->P[1] = Pt.y; h->P[2] = Pt.z;
-                h->n[0] = n.x; h->n[1] = n.y; h->n[2] = n.z;
-                h->e[0] = o.x; h->e[1] = o.y; h->e[2] = o.z;
+                const d3 n2 = unit3(n);
+                const d3 vv = unit3(sub3(o, Pt));
+                h->n[0] = n2.x; h->n[1] = n2.y; h->n[2] = n2.z;
+                h->v[0] = vv.x; h->v[1] = vv.y; h->v[2] = vv.z;
                 h->weight = wloc;
                 h->pixel = pixel;
                 h->prim = prim;
@@ -846,11 +857,11 @@ __global__ __launch_bounds__(256) void k_shadow(FrameParams P, QueueSet Q)
             lit = !occluded;
             if (lit) {
                 const rt_material m = P.S.materials[P.S.prim_material[hr->prim]];
-                const d3 normal = unit3(ld3(hr->n));
+                const d3 normal = ld3(hr->n);
                 if (m.Ks > 0) {
-                    d3 nn = unit3(normal);
-                    d3 v = unit3(sub3(ld3(hr->e), Pt));
-                    d3 lDir = unit3(sub3(lpos, Pt));
+                    d3 nn = unit3(normal);            // third normalisation (Solid.h:153)
+                    d3 v = ld3(hr->v);
+                    d3 lDir = rd;                     // unit3(lpos - Pt), the same value as the shadow ray direction
                     d3 rdir = unit3(add3(neg3(lDir), scale3(2.0 * dot3(lDir, nn), nn)));
                     double a = dot3(rdir, v);
                     double pw = pow((a < 0.0) ? 0.0 : a, m.Shine);
@@ -859,7 +870,7 @@ __global__ __launch_bounds__(256) void k_shadow(FrameParams P, QueueSet Q)
                     local = add3(local, scale3(kfac, comp));
                 }
                 {
-                    double a = dot3(unit3(sub3(lpos, Pt)), normal);
+                    double a = dot3(rd, normal);
                     double dm = (a < 0.0) ? 0.0 : a;
                     double ik = lt->intensity * m.Kd;
                     d3 comp = mk3((ik * m.r) * dm, (ik * m.g) * dm, (ik * m.b) * dm);
@@ -1235,7 +1246,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         const long long blocks_y = ((long long)local_rows + 7) / 8;
         const long long n_chunks = blocks_y * P.blocks_x * (long long)(N * N);
         long long batch_chunks = ctx->batch_override > 0 ? (ctx->batch_override + 63) / 64
-                                                          : (ctx->any_transparent ? (1ll << 21) / 64 : (1ll << 23) / 64);
+                                                          : (ctx->any_transparent ? (1ll << 22) / 64 : (1ll << 26) / 64);
         if (batch_chunks > n_chunks) batch_chunks = n_chunks;
         if (batch_chunks < 1) batch_chunks = 1;
 
