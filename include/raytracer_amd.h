@@ -118,6 +118,8 @@ typedef struct rt_camera {
 #define RT_FLAG_KEEP_ZERO_WEIGHT 4u/* trace reflection rays whose weight is exactly 0, as the
                                       reference does (Camera.h:305-306); they change no pixel */
 #define RT_FLAG_TIMING        8u   /* record per-kernel-class HIP-event times into rt_stats */
+#define RT_FLAG_NO_LIGHTCAM  16u   /* leave the light-camera term out: a point lit only through transparent
+                                      spheres counts as shadowed (it is still marked in lightcam_mask) */
 
 typedef struct rt_render_opts {
     int32_t num_samples;       /* N of `-s N`; samples per pixel = N*N (Camera.h:123-125) */
@@ -145,7 +147,8 @@ typedef struct rt_frame_out {
 typedef struct rt_stats {
     uint64_t closest_rays;     /* calls equivalent to Camera::castRay(ray), Camera.h:318 */
     uint64_t shadow_rays;      /* calls equivalent to checkOccluded3 from Camera.h:404 */
-    uint64_t lightcam_rays;    /* light-camera rays (LightCam.h:491), reported separately */
+    uint64_t lightcam_rays;    /* light-camera rays (LightCam.h:491) traced to build the cameras in use;
+                                  reported separately, not part of the two counts above */
     uint64_t rays_per_generation[6];
     uint64_t hits_per_generation[6];
     double gpu_ms;             /* whole frame, HIP events on the context's stream */

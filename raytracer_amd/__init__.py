@@ -24,6 +24,7 @@ FLAG_PHONG_NORMALS = 1
 FLAG_NO_CULL = 2
 FLAG_KEEP_ZERO_WEIGHT = 4
 FLAG_TIMING = 8
+FLAG_NO_LIGHTCAM = 16
 SPH_TRANSPARENT = 0x80000000
 PRIM_SPHERE = 1
 PRIM_HAS_VNORMALS = 2

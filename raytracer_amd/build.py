@@ -57,14 +57,20 @@ def build_library(force=False):
     dev_obj = os.path.join(CSRC, "rt_device.o")
     host_obj = os.path.join(CSRC, "host_scene.o")
     accel_obj = os.path.join(CSRC, "accel_build.o")
-    if force or _newer(dev_obj, [dev_src, header, accel_hdr, os.path.abspath(__file__)]):
+    lc_src = os.path.join(CSRC, "lightcam_build.cpp")
+    lc_hdr = os.path.join(CSRC, "lightcam_build.hpp")
+    lc_obj = os.path.join(CSRC, "lightcam_build.o")
+    deps += [lc_src, lc_hdr]
+    if force or _newer(lc_obj, [lc_src, lc_hdr, os.path.abspath(__file__)]):
+        _run(["g++"] + HOST_FLAGS + ["-c", lc_src, "-o", lc_obj])
+    if force or _newer(dev_obj, [dev_src, header, accel_hdr, lc_hdr, os.path.abspath(__file__)]):
         _run([hipcc] + DEVICE_FLAGS + ["-c", dev_src, "-o", dev_obj])
     if force or _newer(host_obj, [host_src, header, os.path.join(CSRC, "host_scene.hpp"), os.path.abspath(__file__)]):
         _run(["g++"] + HOST_FLAGS + ["-c", host_src, "-o", host_obj])
     if force or _newer(accel_obj, [accel_src, accel_hdr, header, os.path.abspath(__file__)]):
         _run(["g++"] + HOST_FLAGS + ["-c", accel_src, "-o", accel_obj])
-    if force or _newer(LIB, deps + [dev_obj, host_obj, accel_obj]):
-        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, dev_obj, host_obj, accel_obj])
+    if force or _newer(LIB, deps + [dev_obj, host_obj, accel_obj, lc_obj]):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, dev_obj, host_obj, accel_obj, lc_obj])
     return LIB
 
 

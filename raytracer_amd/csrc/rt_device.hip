@@ -23,6 +23,7 @@
 // are summed can differ from a CPU evaluation.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -32,6 +33,7 @@
 
 #include "../../include/raytracer_amd.h"
 #include "accel_build.hpp"
+#include "lightcam_build.hpp"
 
 // ------------------------------------------------------------------ errors
 namespace {
@@ -94,6 +96,17 @@ struct DevScene {
     const uint32_t *bsph_prim;
     const int32_t *bsph_key;
     int32_t n_tri_nodes, n_sph_nodes;
+    // light cameras (LightCam.h): one per (transparent sphere, light) pair, index rank*n_lights+light
+    const int32_t *prim_lc_rank;          // per primitive: rank among transparent spheres, or -1
+    const struct DevLightCam *lc_table;   // null until the cameras are built
+};
+
+struct DevLightCam {
+    const lightcam::Node *nodes;
+    const lightcam::Point *points;
+    int32_t n_nodes, n_points;
+    double spw;                           // sub-pixel width of the light camera (LightCam.h:223)
+    double light_pos[3], sphere_pos[3];
 };
 
 struct FrameParams {
@@ -255,9 +268,9 @@ DEV double sph_test(const rt_sph_rec *sp, d3 o, d3 d, double d2, double minT, do
 // Closest hit over the flattened octree (Octree.h:996-1062).  `best` is a triangle slot,
 // a sphere slot | SLOT_SPHERE, or -1.  With `cull`, a node whose bounding sphere is entered
 // beyond the current best hit is pruned; the nearest hit is unchanged by that.
-DEV void trace_closest(const DevScene &S, d3 o, d3 d, bool cull, double &best_t, int &best)
+DEV void trace_closest(const DevScene &S, d3 o, d3 d, bool cull, double minT, double &best_t, int &best)
 {
-    const double minT = .01, maxT = 10000000000.0;
+    const double maxT = 10000000000.0;
     const double A = dot3(d, d);
     best_t = maxT;
     best = -1;
@@ -485,6 +498,92 @@ DEV bool root_gate(const DevScene &S, d3 o, d3 d, double d2, double sentinel)
     return !(ret >= sentinel);
 }
 
+// Geometry of a found hit (Solid.h:110-125): primitive id, unit normal, impact point.
+// `best` is a slot of the given record arrays (| SLOT_SPHERE for spheres).
+DEV void hit_geometry(const DevScene &S, const rt_tri_rec *tri_arr, const rt_sph_rec *sph_arr, const uint32_t *sph_prim_arr,
+                      uint32_t flags, d3 o, d3 d, double minT, double t, int best, int *prim_out, d3 *n_out, d3 *P_out)
+{
+    d3 nraw;
+    int prim;
+    if (best & SLOT_SPHERE) {
+        const int s = best & ~SLOT_SPHERE;
+        prim = (int)(sph_prim_arr[s] & ~RT_SPH_TRANSPARENT);
+        const rt_sph_rec *sp = &sph_arr[s];
+        nraw = div3(sub3(add3(o, scale3(t, d)), ld3(sp->center)), sp->radius);
+    } else {
+        const rt_tri_rec *tr = &tri_arr[best];
+        prim = tr->prim;
+        const double *pn = &S.prim_normals[(size_t)prim * 12];
+        nraw = ld3(pn);
+        if ((flags & RT_FLAG_PHONG_NORMALS) && (S.prim_flags[prim] & RT_PRIM_HAS_VNORMALS)) {
+            double al, be;
+            (void)tri_test(tr, o, d, minT, 10000000000.0, &al, &be);
+            d3 n0 = ld3(pn + 3), n1 = ld3(pn + 6), n2 = ld3(pn + 9);
+            nraw = add3(add3(scale3(al, n1), scale3(be, n2)), scale3(1 - (al + be), n0));
+        }
+    }
+    *prim_out = prim;
+    *n_out = unit3(nraw);
+    *P_out = mk3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
+}
+
+// Refraction / total-internal-reflection direction at a transparent hit (Camera.h:260-302,
+// LightCam.h:397-472).  `renormalize` is the light camera's variant (LightCam.h:440).
+DEV d3 refract_dir(d3 d, d3 n, double ior, bool renormalize)
+{
+    d3 nn = n;
+    d3 V = neg3(d);
+    double dt = dot3(nn, V);
+    if (dt >= 0) ior = 1.0 / ior;
+    else { nn = neg3(nn); dt = -dt; }
+    double disc = 1 - (1 - (dt * dt)) * (ior * ior);
+    if (disc > 0) {
+        double sq = sqrt(disc);
+        d3 rd = mk3((nn.x * dt - V.x) * ior - nn.x * sq, (nn.y * dt - V.y) * ior - nn.y * sq,
+                    (nn.z * dt - V.z) * ior - nn.z * sq);
+        return renormalize ? unit3(rd) : rd;
+    }
+    return unit3(add3(d, scale3(2.0 * -dot3(d, nn), nn)));
+}
+
+// LightCam::calcIntensity + getIntensity (LightCam.h:121-203, 571-620): density of light-ray
+// impacts around `pos`, by the reference's descent rule over the point octree.
+DEV double lc_calc_intensity(const DevLightCam &cam, d3 pos)
+{
+    const d3 lp = ld3(cam.light_pos), sp = ld3(cam.sphere_pos);
+    const double smoothingFactor = 1.5;
+    const double dist = norm3(sub3(pos, lp));
+    const double sphereDistToLight = norm3(sub3(lp, sp));
+    double maxDist = cam.spw * (dist / sphereDistToLight);
+    maxDist *= smoothingFactor;
+    double total = 0;
+    if (cam.n_nodes > 0) {
+        // depth-first, children 0..7.  Descent stops at nodes smaller than 2*maxDist, so at most
+        // ~7 pending siblings per level over a dozen levels are ever stacked.
+        int stack[192];
+        int sp_ = 0;
+        stack[sp_++] = 0;
+        while (sp_ > 0) {
+            const lightcam::Node *r = &cam.nodes[stack[--sp_]];
+            if (r->size < maxDist * 2 || r->leaf) {
+                for (int k = r->begin; k < r->end; ++k) {
+                    const lightcam::Point *q = &cam.points[k];
+                    double dd = norm3(sub3(mk3(q->x, q->y, q->z), pos));
+                    if (dd < maxDist) total += q->w;
+                }
+            } else {
+                const double epsilon = maxDist * 0.1;
+                if (norm3(sub3(pos, mk3(r->cx, r->cy, r->cz))) < (r->size + epsilon)) {
+                    for (int c = 7; c >= 0; --c)
+                        if (r->child[c] >= 0 && sp_ < 192) stack[sp_++] = r->child[c];
+                }
+            }
+        }
+    }
+    const double expected = (maxDist * maxDist) / (cam.spw * cam.spw);
+    return total / expected;
+}
+
 // Counter-based stand-in for the reference's shared rand() % 1000 / 1000 (Camera.h:99-103).
 DEV uint32_t hash_rng(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
 {
@@ -695,7 +794,7 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
                 best_t = bst.t;
                 best = bst.slot;
             } else {
-                trace_closest(P.S, o, d, cull, best_t, best);
+                trace_closest(P.S, o, d, cull, .01, best_t, best);
             }
         }
         const rt_tri_rec *tri_arr = BVH ? P.S.btri : P.S.tri;
@@ -714,26 +813,7 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
         rt_material m;
         m.Ks = 0; m.T = 0; m.ior = 1;
         if (hit) {
-            d3 nraw;
-            if (best & SLOT_SPHERE) {
-                const int s = best & ~SLOT_SPHERE;
-                prim = (int)(sph_prim_arr[s] & ~RT_SPH_TRANSPARENT);
-                const rt_sph_rec *sp = &sph_arr[s];
-                nraw = div3(sub3(add3(o, scale3(best_t, d)), ld3(sp->center)), sp->radius);
-            } else {
-                const rt_tri_rec *tr = &tri_arr[best];
-                prim = tr->prim;
-                const double *pn = &P.S.prim_normals[(size_t)prim * 12];
-                nraw = ld3(pn);
-                if ((P.flags & RT_FLAG_PHONG_NORMALS) && (P.S.prim_flags[prim] & RT_PRIM_HAS_VNORMALS)) {
-                    double al, be;
-                    (void)tri_test(tr, o, d, .01, 10000000000.0, &al, &be);
-                    d3 n0 = ld3(pn + 3), n1 = ld3(pn + 6), n2 = ld3(pn + 9);
-                    nraw = add3(add3(scale3(al, n1), scale3(be, n2)), scale3(1 - (al + be), n0));
-                }
-            }
-            n = unit3(nraw);
-            Pt = mk3(o.x + d.x * best_t, o.y + d.y * best_t, o.z + d.z * best_t);
+            hit_geometry(P.S, tri_arr, sph_arr, sph_prim_arr, P.flags, o, d, .01, best_t, best, &prim, &n, &Pt);
             refl = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));
             m = P.S.materials[P.S.prim_material[prim]];
         }
@@ -764,21 +844,7 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
             bool ok;
             uint32_t slot = wave_reserve(want, &Q.counts[CNT_RAYS(Q.generation + 1)], Q.out_shard_cap, &Q.counts[CNT_OVERFLOW], &ok);
             if (ok) {
-                double ior = m.ior;
-                d3 nn = n;
-                d3 V = neg3(d);
-                double dt = dot3(nn, V);
-                if (dt >= 0) ior = 1.0 / ior;
-                else { nn = neg3(nn); dt = -dt; }
-                double disc = 1 - (1 - (dt * dt)) * (ior * ior);
-                d3 rd;
-                if (disc > 0) {
-                    double sq = sqrt(disc);
-                    rd = mk3((nn.x * dt - V.x) * ior - nn.x * sq, (nn.y * dt - V.y) * ior - nn.y * sq,
-                             (nn.z * dt - V.z) * ior - nn.z * sq);
-                } else {
-                    rd = unit3(add3(d, scale3(2.0 * -dot3(d, nn), nn)));
-                }
+                const d3 rd = refract_dir(d, n, m.ior, false);
                 RayRec *r = &Q.rays_out[slot];
                 r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
                 r->d[0] = rd.x; r->d[1] = rd.y; r->d[2] = rd.z;
@@ -849,10 +915,18 @@ __global__ __launch_bounds__(256) void k_shadow(FrameParams P, QueueSet Q)
             } else {
                 occluded = trace_shadow(P.S, Pt, rd, hr->prim, maxT, cull, &only, &closest);
             }
-            const double kfac = .999999;
+            double kfac = .999999;
             if (occluded && only) {
-                // shadowed by transparent spheres only: the reference consults its light camera here
+                // shadowed by transparent spheres only: the light camera of (that sphere, this light)
+                // decides how much light arrives (Camera.h:406-451)
                 if (P.lc_mask) P.lc_mask[pixel] = 1;
+                if (P.S.lc_table && closest >= 0) {
+                    const int rank = P.S.prim_lc_rank[closest];
+                    if (rank >= 0) {
+                        kfac = lc_calc_intensity(P.S.lc_table[rank * P.S.n_lights + li], Pt);
+                        if (kfac > .01) occluded = false;
+                    }
+                }
             }
             lit = !occluded;
             if (lit) {
@@ -880,6 +954,79 @@ __global__ __launch_bounds__(256) void k_shadow(FrameParams P, QueueSet Q)
         }
         accum_add_runs(P.accum, active, lit, pixel, hr->weight, local);
     }
+}
+
+// Light rays of one light camera (LightCam::lightCast, recursiveCastLightRays, castLightRay:
+// LightCam.h:207-306, 340-556).  One lane per sub-pixel (si, sj) of the N x N grid; each lane follows
+// its refraction / total-internal-reflection chain and writes every impact into its own row of
+// `slots` (21 entries: the first hit plus a depth budget of 20), so the host can read them back in
+// the reference's order.
+struct PhotonParams {
+    DevScene S;
+    double u[3], v[3], w[3], e[3];
+    double d, l, t, pix_width;
+    int32_t N;
+    uint32_t flags;
+    int32_t cull;
+    lightcam::Point *slots;     // N*N rows of 21
+    int32_t *counts;            // N*N
+};
+#define LC_MAX_IMPACTS 21
+
+__global__ __launch_bounds__(256) void k_photons(PhotonParams Q)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)Q.N * Q.N;
+    if (idx >= total) return;
+    const int si = (int)(idx / Q.N), sj = (int)(idx - (long long)si * Q.N);
+    const double spw = Q.pix_width / Q.N;
+    double p, q;
+    if (Q.N > 1) {
+        const double edgeX = (0 - .5) * Q.pix_width;
+        const double edgeY = (0 - .5) * Q.pix_width;
+        const double j_m = edgeX + sj * spw + .5 * spw;
+        const double i_m = edgeY + si * spw + .5 * spw;
+        p = Q.l + j_m;
+        q = Q.t - i_m;
+    } else {
+        p = Q.l + 0 * Q.pix_width;
+        q = Q.t - 0 * Q.pix_width;
+    }
+    const double r = -Q.d;
+    d3 d = unit3(add3(add3(scale3(p, ld3(Q.u)), scale3(q, ld3(Q.v))), scale3(r, ld3(Q.w))));
+    d3 o = ld3(Q.e);
+    double coef = 1.0, CoR = 1.0;
+    int budget = 20, n_out = 0, calls = 0;
+    bool top = true;
+    lightcam::Point *row = Q.slots + idx * LC_MAX_IMPACTS;
+    while (n_out < LC_MAX_IMPACTS) {
+        ++calls;                                                   // one castLightRay call
+        if (!(coef > .05)) break;                                  // LightCam.h:502
+        double t;
+        int best;
+        trace_closest(Q.S, o, d, Q.cull != 0, .000001, t, best);    // selfIntersectBias 1e-6, LightCam.h:44
+        if (best < 0) break;
+        int prim;
+        d3 n, Pt;
+        hit_geometry(Q.S, Q.S.tri, Q.S.sph, Q.S.sph_prim, Q.flags, o, d, .000001, t, best, &prim, &n, &Pt);
+        const rt_material m = Q.S.materials[Q.S.prim_material[prim]];
+        lightcam::Point pt;
+        pt.x = Pt.x; pt.y = Pt.y; pt.z = Pt.z;
+        pt.w = coef * (1.0 - m.T);                                 // LightCam.h:536
+        row[n_out++] = pt;
+        if (top && !(best & SLOT_SPHERE)) break;                    // LightCam.h:360
+        if (budget <= 0) break;
+        CoR *= m.Ks;                                               // LightCam.h:380
+        if (coef < .01) break;
+        if (CoR < .01 && m.T == 0) break;
+        if (!(m.T > 0)) break;                                     // only refraction continues the chain
+        d = refract_dir(d, n, m.ior, true);
+        o = Pt;
+        coef = coef * m.T;
+        budget -= 1;
+        top = false;
+    }
+    Q.counts[idx] = n_out | (calls << 8);
 }
 
 // totals[0]=closest rays, [1]=shadow rays, [2..7]=rays per generation (generation 0 is filled in by the
@@ -933,6 +1080,13 @@ struct rt_ctx {
     bool any_transparent_sphere = false;
     bool spheres_inside_root = true;       // every sphere lies inside the root cube
     bool accel_usable = false;             // hierarchies built and shallow enough for the LDS stack
+    // host copies needed to set up the light cameras
+    std::vector<rt_light> h_lights;
+    std::vector<std::array<double, 4>> h_lc_spheres;   // centre + radius of every transparent sphere, by rank
+    std::vector<void *> lc_allocs;
+    bool lc_built = false;
+    uint32_t lc_built_flags = 0;
+    unsigned long long lc_rays = 0;
     int32_t lightcam_samples = 150;
     // frame resources (grow-only)
     double *accum = nullptr; size_t accum_values = 0;
@@ -952,8 +1106,18 @@ struct rt_ctx {
     int cu_count = 256;
 };
 
+static void free_lightcams(rt_ctx *ctx)
+{
+    for (void *p : ctx->lc_allocs) (void)hipFree(p);
+    ctx->lc_allocs.clear();
+    ctx->lc_built = false;
+    ctx->S.lc_table = nullptr;
+    ctx->lc_rays = 0;
+}
+
 static int free_scene(rt_ctx *ctx)
 {
+    free_lightcams(ctx);
     for (void *p : ctx->scene_allocs) (void)hipFree(p);
     ctx->scene_allocs.clear();
     ctx->has_scene = false;
@@ -1099,6 +1263,20 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     if ((rc = upload(ctx, s->prim_normals, (size_t)s->n_prims * 12, &D.prim_normals)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->materials, (size_t)s->n_materials, &D.materials)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->lights, (size_t)s->n_lights, &D.lights)) != RT_OK) return rc;
+    {
+        std::vector<int32_t> rank(static_cast<size_t>(s->n_prims), -1);
+        ctx->h_lc_spheres.clear();
+        for (int32_t i = 0; i < s->n_sph_slots; ++i) {
+            if (!(s->sph_prim[i] & RT_SPH_TRANSPARENT)) continue;
+            const int32_t p = static_cast<int32_t>(s->sph_prim[i] & ~RT_SPH_TRANSPARENT);
+            if (rank[p] >= 0) continue;
+            rank[p] = static_cast<int32_t>(ctx->h_lc_spheres.size());
+            ctx->h_lc_spheres.push_back({s->sph[i].center[0], s->sph[i].center[1], s->sph[i].center[2], s->sph[i].radius});
+        }
+        if ((rc = upload(ctx, rank.data(), rank.size(), &D.prim_lc_rank)) != RT_OK) return rc;
+        ctx->h_lights.assign(s->lights, s->lights + s->n_lights);
+    }
+    D.lc_table = nullptr;
     D.n_nodes = s->n_nodes;
     D.n_lights = s->n_lights;
     D.bg[0] = s->background[0]; D.bg[1] = s->background[1]; D.bg[2] = s->background[2];
@@ -1168,6 +1346,103 @@ static std::pair<hipEvent_t, hipEvent_t> *next_event_pair(std::vector<std::pair<
     return &v[used++];
 }
 
+// Builds the light camera of every (transparent sphere, light) pair: photon pass on the device,
+// point octree on the host (lightcam_build.cpp), flattened tree back to the device.  The reference
+// creates a camera the first time a shading point needs it (Camera.h:417-440); a camera depends
+// only on its pair, so building all of them ahead changes no pixel.
+#define LC_MAX_PAIRS 64
+static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
+{
+    free_lightcams(ctx);
+    const size_t n_pairs = ctx->h_lc_spheres.size() * ctx->h_lights.size();
+    if (n_pairs == 0 || n_pairs > LC_MAX_PAIRS) return RT_OK;   // beyond the cap the term stays off (masked)
+    const int N = ctx->lightcam_samples;
+    if (N < 1 || N > 4096) return fail(RT_ERR_INVALID, "light camera sample count (Z) must be in 1..4096");
+    const size_t n_rays = (size_t)N * N;
+    lightcam::Point *d_slots = nullptr;
+    int32_t *d_counts = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_slots, n_rays * LC_MAX_IMPACTS * sizeof(lightcam::Point)));
+    if (hipMalloc((void **)&d_counts, n_rays * sizeof(int32_t)) != hipSuccess) {
+        (void)hipFree(d_slots);
+        return fail(RT_ERR_DEVICE, "hipMalloc failed for the light-camera counts");
+    }
+    std::vector<lightcam::Point> h_slots(n_rays * LC_MAX_IMPACTS);
+    std::vector<int32_t> h_counts(n_rays);
+    std::vector<DevLightCam> table(n_pairs);
+    int rc = RT_OK;
+    for (size_t r = 0; r < ctx->h_lc_spheres.size() && rc == RT_OK; ++r)
+        for (size_t li = 0; li < ctx->h_lights.size() && rc == RT_OK; ++li) {
+            const auto &sp = ctx->h_lc_spheres[r];
+            const rt_light &lt = ctx->h_lights[li];
+            lightcam::Frame fr;
+            const double spos[3] = {sp[0], sp[1], sp[2]};
+            lightcam::setup_frame(lt.pos, spos, sp[3], fr);
+            PhotonParams Q{};
+            Q.S = ctx->S;
+            for (int k = 0; k < 3; ++k) { Q.u[k] = fr.u[k]; Q.v[k] = fr.v[k]; Q.w[k] = fr.w[k]; Q.e[k] = fr.e[k]; }
+            Q.d = fr.d; Q.l = fr.l; Q.t = fr.t; Q.pix_width = fr.pix_width;
+            Q.N = N;
+            Q.flags = flags;
+            Q.cull = cull ? 1 : 0;
+            Q.slots = d_slots;
+            Q.counts = d_counts;
+            hipLaunchKernelGGL(k_photons, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, ctx->stream, Q);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+                hipMemcpy(h_counts.data(), d_counts, n_rays * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(h_slots.data(), d_slots, h_slots.size() * sizeof(lightcam::Point), hipMemcpyDeviceToHost) != hipSuccess) {
+                rc = fail(RT_ERR_DEVICE, "light-camera photon pass failed");
+                break;
+            }
+            std::vector<lightcam::Point> pts;
+            double max_dist = 0;
+            for (size_t i = 0; i < n_rays; ++i) {
+                const int n = h_counts[i] & 0xff;
+                ctx->lc_rays += (unsigned long long)(h_counts[i] >> 8);
+                for (int k = 0; k < n; ++k) {
+                    const lightcam::Point &p = h_slots[i * LC_MAX_IMPACTS + k];
+                    pts.push_back(p);
+                    const double dz = lightcam::length3(p.x, p.y, p.z);
+                    if (dz > max_dist) max_dist = dz;     // std::max(distToOrigin, maxDistFromZero)
+                }
+            }
+            lightcam::Tree tree;
+            lightcam::build(pts, max_dist, tree);
+            DevLightCam cam{};
+            void *dn = nullptr, *dp = nullptr;
+            if (hipMalloc(&dn, sizeof(lightcam::Node) * (tree.nodes.size() ? tree.nodes.size() : 1)) != hipSuccess ||
+                hipMalloc(&dp, sizeof(lightcam::Point) * (tree.points.size() ? tree.points.size() : 1)) != hipSuccess) {
+                if (dn) (void)hipFree(dn);
+                rc = fail(RT_ERR_DEVICE, "hipMalloc failed for a light-camera tree");
+                break;
+            }
+            ctx->lc_allocs.push_back(dn);
+            ctx->lc_allocs.push_back(dp);
+            if (hipMemcpy(dn, tree.nodes.data(), sizeof(lightcam::Node) * tree.nodes.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(dp, tree.points.data(), sizeof(lightcam::Point) * tree.points.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                rc = fail(RT_ERR_DEVICE, "upload of a light-camera tree failed");
+                break;
+            }
+            cam.nodes = static_cast<const lightcam::Node *>(dn);
+            cam.points = static_cast<const lightcam::Point *>(dp);
+            cam.n_nodes = (int32_t)tree.nodes.size();
+            cam.n_points = (int32_t)tree.points.size();
+            cam.spw = fr.pix_width / N;
+            for (int k = 0; k < 3; ++k) { cam.light_pos[k] = lt.pos[k]; cam.sphere_pos[k] = spos[k]; }
+            table[r * ctx->h_lights.size() + li] = cam;
+        }
+    (void)hipFree(d_slots);
+    (void)hipFree(d_counts);
+    if (rc != RT_OK) { free_lightcams(ctx); return rc; }
+    void *dt = nullptr;
+    HIP_TRY(hipMalloc(&dt, sizeof(DevLightCam) * n_pairs));
+    ctx->lc_allocs.push_back(dt);
+    HIP_TRY(hipMemcpy(dt, table.data(), sizeof(DevLightCam) * n_pairs, hipMemcpyHostToDevice));
+    ctx->S.lc_table = static_cast<const DevLightCam *>(dt);
+    ctx->lc_built = true;
+    ctx->lc_built_flags = flags;
+    return RT_OK;
+}
+
 static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *o, const rt_frame_out *out,
                          bool outputs_on_device)
 {
@@ -1186,8 +1461,19 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const size_t n_pixels = (size_t)local_rows * cam->resx;
     if (n_pixels >= (size_t)1 << 31) return fail(RT_ERR_INVALID, "rt_render: more than 2^31 pixels in one part");
 
+    const bool may_cull = !(o->flags & RT_FLAG_NO_CULL) && ctx->spheres_inside_root;
+    {
+        // light cameras: built once per scene (and per normal-interpolation mode, which the light rays see)
+        const uint32_t lc_flags = o->flags & RT_FLAG_PHONG_NORMALS;
+        const bool want_lc = !(o->flags & RT_FLAG_NO_LIGHTCAM) && ctx->any_transparent_sphere && !ctx->h_lights.empty();
+        if (want_lc && (!ctx->lc_built || ctx->lc_built_flags != lc_flags)) {
+            int rc = build_lightcams(ctx, lc_flags, may_cull);
+            if (rc != RT_OK) return rc;
+        }
+    }
     FrameParams P{};
     P.S = ctx->S;
+    if (o->flags & RT_FLAG_NO_LIGHTCAM) P.S.lc_table = nullptr;
     P.cam = *cam;
     P.N = N;
     P.aperture = o->aperture;
@@ -1198,7 +1484,6 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     P.part = o->part;
     P.local_rows = local_rows;
     P.blocks_x = (cam->resx + 7) / 8;
-    const bool may_cull = !(o->flags & RT_FLAG_NO_CULL) && ctx->spheres_inside_root;
     P.cull_closest = may_cull ? 1 : 0;
     P.cull_shadow = (may_cull && !ctx->any_transparent_sphere) ? 1 : 0;
     // The hierarchies answer "nearest / any hit over all primitives"; that equals the reference's
@@ -1354,6 +1639,7 @@ extern "C" int rt_sync(rt_ctx *ctx, rt_stats *stats)
         tot[0] += ctx->pending_primaries;   // generation 0 is counted on the host
         tot[2] = ctx->pending_primaries;
         stats->closest_rays = tot[0];
+        stats->lightcam_rays = ctx->lc_rays;
         stats->shadow_rays = tot[1];
         for (int g = 0; g < 6; ++g) { stats->rays_per_generation[g] = tot[2 + g]; stats->hits_per_generation[g] = tot[8 + g]; }
         stats->queue_overflow = tot[15] ? 1 : 0;

@@ -87,7 +87,7 @@ def test_transparent_sphere_scenes_without_light_camera(gpu, oracle_frame, scene
     """Scenes whose shadow rays meet transparent spheres: exact checkOccluded3 ordering.
     The light-camera term itself is switched off on both sides (shadowed instead)."""
     s = load_scene(gpu, scene)
-    g = gpu.render(s.camera(), flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    g = gpu.render(s.camera(), flags=rt.FLAG_KEEP_ZERO_WEIGHT | rt.FLAG_NO_LIGHTCAM)
     o = oracle_frame(scene, flags=ob.FLAG_NO_LIGHTCAM)
     assert_frames_match(g, o)
     assert np.array_equal(g["lightcam_mask"], o["lightcam_mask"])
@@ -99,9 +99,43 @@ def test_transparent_sphere_scenes_without_light_camera(gpu, oracle_frame, scene
 @pytest.mark.parametrize("scene", ["2d", "teapot-1", "glass3", "ball", "tetra-5", "teapot-2"])
 def test_small_scenes(gpu, oracle_frame, scene):
     s = load_scene(gpu, scene)
-    g = gpu.render(s.camera())
+    g = gpu.render(s.camera(), flags=rt.FLAG_NO_LIGHTCAM)
     o = oracle_frame(scene, flags=ob.FLAG_NO_LIGHTCAM)
     assert_frames_match(g, o)
+
+
+def test_glass_matches_the_reference_golden_image(gpu, oracle_frame):
+    """glass.nff with the light-camera caustics on the device: against the oracle and against
+    hide.ppm, the image the reference's authors committed."""
+    import gzip
+    import os
+    s = load_scene(gpu, "glass")
+    g = gpu.render(s.camera(), flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    o = oracle_frame("glass")
+    assert_frames_match(g, o, tol=1e-6)
+    assert np.array_equal(g["lightcam_mask"], o["lightcam_mask"])
+    assert g["stats"]["closest_rays"] == o["counters"]["closest_rays"]
+    assert g["stats"]["shadow_rays"] == o["counters"]["shadow_rays"]
+    assert g["stats"]["lightcam_rays"] == sum(c["light_rays"] for c in o["lightcams"])
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hide.ppm.gz"), "rb") as f:
+        ref = f.read()
+    header = b"P6\n900 900\n255\n"
+    assert ref.startswith(header)
+    golden = np.frombuffer(ref[len(header):], dtype=np.uint8).reshape(900, 900, 3)
+    within = (np.abs(g["rgb_u8"].astype(np.int32) - golden.astype(np.int32)).max(axis=2) <= 1).mean()
+    assert within >= 0.999
+    assert np.array_equal(g["rgb_u8"], golden), "%d bytes differ from hide.ppm" % int((g["rgb_u8"] != golden).sum())
+
+
+@pytest.mark.parametrize("scene", ["glass2", "glass3"])
+def test_light_camera_scenes(gpu, oracle_frame, scene):
+    s = load_scene(gpu, scene)
+    g = gpu.render(s.camera(), flags=rt.FLAG_KEEP_ZERO_WEIGHT)   # the mask also records zero-weight rays' shading points
+    o = oracle_frame(scene)
+    assert_frames_match(g, o, tol=1e-6)
+    assert np.array_equal(g["lightcam_mask"], o["lightcam_mask"])
+    fast = gpu.render(s.camera())
+    assert np.array_equal(fast["rgb_u8"], g["rgb_u8"])
 
 
 def test_supersampling_and_depth_of_field(gpu, oracle_frame):
