@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--workload", default="teapot3_8k16", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra RT_FLAG_* bits for the render calls")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N>1; gloo (frame staged through host memory) is only for rehearsing "
+                         "several ranks on one GPU, where RCCL refuses duplicate devices")
     args = ap.parse_args()
 
     import torch
@@ -98,12 +101,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; if the launcher already narrowed the visible devices to one, use that one
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     scene_name, resx, resy, N, dsteps, dwarm = WORKLOADS[args.workload]
     steps = args.steps if args.steps is not None else dsteps
@@ -112,19 +120,23 @@ def main():
     scene = rt.Scene.load(scene_name)
     cam = scene.camera(resx, resy)
     resx, resy = cam.resx, cam.resy
-    gpu = rt.Renderer(local_rank)
+    gpu = rt.Renderer(dev_index)
     gpu.upload(scene)
 
     from raytracer_amd.multi import FrameGather
     band = BAND_ROWS if world > 1 else 0
-    dev = torch.device("cuda", local_rank)
-    fg = FrameGather(resx, resy, band, world, rank, dev, dist)
+    dev = torch.device("cuda", dev_index)
+    staged = world > 1 and args.backend == "gloo"
+    fg = FrameGather(resx, resy, band, world, rank, torch.device("cpu") if staged else dev, dist)
     assert fg.local_rows == rt.part_rows(cam, band, world, rank)
+    render_buf = torch.zeros_like(fg.local, device=dev) if staged else fg.local
 
     def step(flags):
-        st = gpu.render_device(cam, rgb_u8_ptr=fg.local.data_ptr(), num_samples=N, flags=flags, band_rows=band,
+        st = gpu.render_device(cam, rgb_u8_ptr=render_buf.data_ptr(), num_samples=N, flags=flags, band_rows=band,
                                n_parts=world, part=rank)
         if world > 1:
+            if staged:
+                fg.local.copy_(render_buf)
             fg.gather()
         return st
 
@@ -198,7 +210,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "scene": scene_name + ".nff", "resolution": [resx, resy],
                        "spp": N * N, "rays_per_frame": rays / steps,
-                       "partition": "%d-row bands round-robin over %d GPU(s), RCCL gather of RGB8" % (band or resy, world)},
+                       "partition": "%d-row bands round-robin over %d GPU(s), %s gather of RGB8"
+                                    % (band or resy, world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal)")},
         }
         if roofline is not None:
             line["roofline"] = roofline

@@ -17,7 +17,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "libraytracer_amd.so")
+LIB_PATH = os.environ.get("RAYTRACER_AMD_LIB") or os.path.join(_PKG, "libraytracer_amd.so")
 
 RT_OK = 0
 FLAG_PHONG_NORMALS = 1

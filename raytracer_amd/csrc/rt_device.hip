@@ -26,6 +26,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -692,10 +693,14 @@ DEV void accum_add_runs(double *accum, bool in_queue, bool valid, uint32_t pixel
 }
 
 // ------------------------------------------------------------------ kernels
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 1
+#endif
 template <bool PRIMARY, bool BVH>
-__global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, QueueSet Q)
 {
-    __shared__ int s_stack[BVH ? BVH_STACK * 256 : 1];
+    // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
+    extern __shared__ int s_stack[];
     int *stack = &s_stack[BVH ? threadIdx.x : 0];
     const int lane = (int)(threadIdx.x & 63);
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -873,9 +878,10 @@ __global__ __launch_bounds__(256) void k_closest(FrameParams P, QueueSet Q)
 }
 
 template <bool BVH>
-__global__ __launch_bounds__(256) void k_shadow(FrameParams P, QueueSet Q)
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void k_shadow(FrameParams P, QueueSet Q)
 {
-    __shared__ int s_stack[BVH ? BVH_STACK * 256 : 1];
+    // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
+    extern __shared__ int s_stack[];
     int *stack = &s_stack[BVH ? threadIdx.x : 0];
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
@@ -1080,6 +1086,7 @@ struct rt_ctx {
     bool any_transparent_sphere = false;
     bool spheres_inside_root = true;       // every sphere lies inside the root cube
     bool accel_usable = false;             // hierarchies built and shallow enough for the LDS stack
+    int accel_depth = 0;                   // deepest hierarchy, in nodes: the stack entries a ray can need
     // host copies needed to set up the light cameras
     std::vector<rt_light> h_lights;
     std::vector<std::array<double, 4>> h_lc_spheres;   // centre + radius of every transparent sphere, by rank
@@ -1165,6 +1172,16 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
     HIP_TRY(hipEventCreate(&ctx->ev_end));
     HIP_TRY(hipMalloc((void **)&ctx->counts, CNT_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->totals, 16 * sizeof(unsigned long long)));
+    if (getenv("RT_DEBUG")) {
+        int n = 0;
+        for (size_t lds : {(size_t)0, (size_t)12 * 1024, (size_t)32 * 1024}) {
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_closest<true, true>, 256, lds);
+            fprintf(stderr, "[rt] k_closest<primary,bvh> lds=%zu: %d blocks/CU\n", lds, n);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shadow<true>, 256, lds);
+            fprintf(stderr, "[rt] k_shadow<bvh> lds=%zu: %d blocks/CU\n", lds, n);
+        }
+        fprintf(stderr, "[rt] CUs=%d\n", ctx->cu_count);
+    }
     *out = ctx;
     return RT_OK;
 }
@@ -1256,6 +1273,7 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     D.n_tri_nodes = (int32_t)acc.tri_bvh.nodes.size();
     D.n_sph_nodes = (int32_t)acc.sph_bvh.nodes.size();
     ctx->accel_usable = acc.usable;
+    ctx->accel_depth = acc.tri_bvh.max_depth > acc.sph_bvh.max_depth ? acc.tri_bvh.max_depth : acc.sph_bvh.max_depth;
     if ((rc = upload(ctx, s->sph, (size_t)s->n_sph_slots, &D.sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->sph_prim, (size_t)s->n_sph_slots, &D.sph_prim)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->prim_flags, (size_t)s->n_prims, &D.prim_flags)) != RT_OK) return rc;
@@ -1491,6 +1509,12 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     // transparent sphere exists (checkOccluded3 is then order-free).
     const bool bvh_closest_ok = may_cull && ctx->accel_usable;
     const bool bvh_shadow_ok = bvh_closest_ok && !ctx->any_transparent_sphere;
+    // one pending sibling per level at most, so depth+1 entries always suffice (BVH_STACK is the cap)
+    int stack_entries = ctx->accel_depth + 1;
+    if (stack_entries > BVH_STACK) stack_entries = BVH_STACK;
+    if (stack_entries < 4) stack_entries = 4;
+    const size_t lds_closest = bvh_closest_ok ? (size_t)stack_entries * 256 * sizeof(int) : 0;
+    const size_t lds_shadow = bvh_shadow_ok ? (size_t)stack_entries * 256 * sizeof(int) : 0;
 
     hipStream_t st = ctx->stream;
     HIP_TRY(hipEventRecord(ctx->ev_begin, st));
@@ -1587,10 +1611,10 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 if (g == 0) {
                     long long blocks = (t1 - t0 + 3) / 4;
                     if (blocks > blocks0) blocks = blocks0;
-                    if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q);
+                    if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(256), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q);
                 } else {
-                    if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<false, true>), dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
+                    if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<false, true>), dim3((unsigned)max_blocks), dim3(256), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<false, false>), dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
                 }
                 if (ev) HIP_TRY(hipEventRecord(ev->second, st));
@@ -1599,7 +1623,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     if (timing && !(ev = next_event_pair(ctx->ev_shadow, ctx->ev_shadow_used)))
                         return fail(RT_ERR_DEVICE, "hipEventCreate failed");
                     if (ev) HIP_TRY(hipEventRecord(ev->first, st));
-                    if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
+                    if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, st, P, Q);
                     else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
                     if (ev) HIP_TRY(hipEventRecord(ev->second, st));
                 }
