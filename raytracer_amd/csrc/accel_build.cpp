@@ -205,6 +205,93 @@ private:
 
 }  // namespace
 
+
+// ---- 4-wide collapse ----
+namespace {
+
+struct Child4 {
+    int32_t code;            // code in the binary tree (inner index, leaf code)
+    double lo[3], hi[3];
+};
+
+float round_down(double x)
+{
+    float f = static_cast<float>(x);
+    if (static_cast<double>(f) > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+float round_up(double x)
+{
+    float f = static_cast<float>(x);
+    if (static_cast<double>(f) < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+double box_area(const Child4 &c)
+{
+    double e[3] = {c.hi[0] - c.lo[0], c.hi[1] - c.lo[1], c.hi[2] - c.lo[2]};
+    return 2 * (e[0] * e[1] + e[1] * e[2] + e[2] * e[0]);
+}
+
+int32_t collapse_node(const Bvh &b2, int32_t idx2, Bvh4 &out, int depth)
+{
+    out.max_depth = std::max(out.max_depth, depth);
+    const int32_t me = static_cast<int32_t>(out.nodes.size());
+    out.nodes.emplace_back();
+    std::vector<Child4> kids;
+    auto add_children_of = [&](int32_t n2) {
+        const BvhNode &nd = b2.nodes[n2];
+        for (int s = 0; s < 2; ++s) {
+            if (nd.child[s] == -1) continue;
+            Child4 c;
+            c.code = nd.child[s];
+            for (int k = 0; k < 3; ++k) { c.lo[k] = nd.lo[s][k]; c.hi[k] = nd.hi[s][k]; }
+            kids.push_back(c);
+        }
+    };
+    add_children_of(idx2);
+    // open the inner child with the largest box while there is room for its two children
+    while (kids.size() < 4) {
+        int pick = -1;
+        double best = -1;
+        for (size_t i = 0; i < kids.size(); ++i)
+            if (kids[i].code >= 0 && box_area(kids[i]) > best) { best = box_area(kids[i]); pick = static_cast<int>(i); }
+        if (pick < 0) break;
+        const int32_t open = kids[pick].code;
+        kids.erase(kids.begin() + pick);
+        add_children_of(open);
+    }
+    Bvh4Node nd;
+    std::memset(&nd, 0, sizeof nd);
+    for (int c = 0; c < 4; ++c) {
+        nd.child[c] = -1;
+        for (int k = 0; k < 3; ++k) { nd.lo[k][c] = 1.0f; nd.hi[k][c] = -1.0f; }
+    }
+    for (size_t c = 0; c < kids.size(); ++c) {
+        for (int k = 0; k < 3; ++k) {
+            nd.lo[k][c] = round_down(kids[c].lo[k]);
+            nd.hi[k][c] = round_up(kids[c].hi[k]);
+            out.max_abs_coord = std::max({out.max_abs_coord, std::fabs(kids[c].lo[k]), std::fabs(kids[c].hi[k])});
+        }
+        nd.child[c] = kids[c].code;   // leaf codes pass through; inner codes are rewritten below
+    }
+    out.nodes[me] = nd;
+    for (size_t c = 0; c < kids.size(); ++c)
+        if (kids[c].code >= 0) {
+            const int32_t sub = collapse_node(b2, kids[c].code, out, depth + 1);
+            out.nodes[me].child[c] = sub;
+        }
+    return me;
+}
+
+void collapse(const Bvh &b2, Bvh4 &out)
+{
+    out = Bvh4();
+    if (b2.nodes.empty()) return;
+    collapse_node(b2, 0, out, 1);
+}
+
+}  // namespace
+
 void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_tri, std::vector<int32_t> &octree_sph_key)
 {
     out = Accel();
@@ -266,8 +353,11 @@ void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_t
         out.sph_prim.push_back(d.sph_prim[it.src]);
         out.sph_key.push_back(octree_sph_key[it.src]);
     }
-    out.usable = out.tri_bvh.max_depth <= 32 && out.sph_bvh.max_depth <= 32 && out.tri.size() < (1u << 28) &&
-                 out.sph.size() < (1u << 28);
+    collapse(out.tri_bvh, out.tri_bvh4);
+    collapse(out.sph_bvh, out.sph_bvh4);
+    // a walk stacks at most three siblings per 4-wide level
+    out.usable = 3 * out.tri_bvh4.max_depth + 1 <= 64 && 3 * out.sph_bvh4.max_depth + 1 <= 64 &&
+                 out.tri.size() < (1u << 28) && out.sph.size() < (1u << 28);
 }
 
 }  // namespace accel

@@ -26,11 +26,28 @@ static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
 struct Bvh {
     std::vector<BvhNode> nodes;   // node 0 is the root; empty when there are no primitives
     int32_t max_depth = 0;
-    // root box (for the single-leaf / empty cases the root node still has two child slots)
+};
+
+// The device walks a 4-wide form of the same tree: every node holds the boxes of up to four
+// children as single-precision bounds rounded OUTWARD (lo down, hi up), child-major per axis,
+// so one 128-byte record answers two levels of the binary tree.  Codes as in BvhNode::child.
+struct Bvh4Node {
+    float lo[3][4];
+    float hi[3][4];
+    int32_t child[4];
+    int32_t _pad[4];
+};
+static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
+
+struct Bvh4 {
+    std::vector<Bvh4Node> nodes;  // node 0 is the root; empty when there are no primitives
+    int32_t max_depth = 0;        // in 4-wide nodes; a walk stacks at most 3 siblings per level
+    double max_abs_coord = 0;     // largest |coordinate| of any box: scales the rounding pad of the slab test
 };
 
 struct Accel {
     Bvh tri_bvh, sph_bvh;
+    Bvh4 tri_bvh4, sph_bvh4;
     std::vector<rt_tri_rec> tri;        // leaf-ordered; _pad0 = tie-break key, _pad1[0] = ab.y*ac.z - ac.y*ab.z
     std::vector<rt_sph_rec> sph;        // leaf-ordered
     std::vector<uint32_t> sph_prim;     // primitive id | RT_SPH_TRANSPARENT

@@ -90,13 +90,14 @@ struct DevScene {
     int32_t n_nodes, n_lights;
     double bg[3];
     // derived hierarchies (accel_build.hpp); leaf records share the layout of the octree slots
-    const accel::BvhNode *tri_nodes;
+    const accel::Bvh4Node *tri_nodes;
     const rt_tri_rec *btri;
-    const accel::BvhNode *sph_nodes;
+    const accel::Bvh4Node *sph_nodes;
     const rt_sph_rec *bsph;
     const uint32_t *bsph_prim;
     const int32_t *bsph_key;
     int32_t n_tri_nodes, n_sph_nodes;
+    float bvh_bound;                      // largest |coordinate| of any hierarchy box
     // light cameras (LightCam.h): one per (transparent sphere, light) pair, index rank*n_lights+light
     const int32_t *prim_lc_rank;          // per primitive: rank among transparent spheres, or -1
     const struct DevLightCam *lc_table;   // null until the cameras are built
@@ -364,30 +365,94 @@ DEV bool trace_shadow(const DevScene &S, d3 o, d3 d, int parent, double maxT, bo
 // ------------------------------------------------------------------ hierarchy traversal
 // Stack of pending nodes in LDS: entry k of a lane lives at stack[k * 256 + lane-in-block], so a
 // wave's push or pop touches 64 consecutive banks.
-#define BVH_STACK 32
+#define BVH_STACK 64
+#define BVH_NONE (-1)
+DEV int leaf_begin(int code) { return (-2 - code) >> 2; }
+DEV int leaf_count(int code) { return ((-2 - code) & 3) + 1; }
 
-struct RayBox {
-    d3 o, inv;
+// Single-precision view of a ray for the slab tests.  The boxes are already rounded outward; what
+// is left to cover is the rounding of the origin, of the subtractions and of the reciprocal.  The
+// first two are spatial errors of at most 2^-23 (|o| + |plane|): the origin is shifted by `pad`
+// (eight times that) towards each plane's conservative side.  The products carry a relative error
+// of a few 2^-24, covered by the factors (1 -+ 2^-20) in box4_hits.
+struct RayBox4 {
+    float olx, oly, olz;   // origin + pad, used against the `lo` planes
+    float ohx, ohy, ohz;   // origin - pad, used against the `hi` planes
+    float ix, iy, iz;      // 1 / direction
 };
-DEV RayBox make_raybox(d3 o, d3 d)
+DEV float inv_dir(double d)
 {
-    RayBox r;
-    r.o = o;
-    // an exactly axis-parallel ray is nudged by 1e-150 for the box test only (0 * inf would be NaN)
-    r.inv.x = 1.0 / (fabs(d.x) < 1e-150 ? (d.x < 0 ? -1e-150 : 1e-150) : d.x);
-    r.inv.y = 1.0 / (fabs(d.y) < 1e-150 ? (d.y < 0 ? -1e-150 : 1e-150) : d.y);
-    r.inv.z = 1.0 / (fabs(d.z) < 1e-150 ? (d.z < 0 ? -1e-150 : 1e-150) : d.z);
+    // an (almost) axis-parallel ray is nudged for the box test only: 0 * inf would be NaN
+    const double dd = fabs(d) < 1e-30 ? (d < 0 ? -1e-30 : 1e-30) : d;
+    return (float)(1.0 / dd);
+}
+DEV RayBox4 make_raybox4(d3 o, d3 d, float bound)
+{
+    RayBox4 r;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    const float pad = 0x1p-21f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + bound);
+    r.olx = ox + pad; r.oly = oy + pad; r.olz = oz + pad;
+    r.ohx = ox - pad; r.ohy = oy - pad; r.ohz = oz - pad;
+    r.ix = inv_dir(d.x); r.iy = inv_dir(d.y); r.iz = inv_dir(d.z);
     return r;
 }
-// Slab test against child `s` of a node; returns entry distance or a value > limit when missed.
-DEV double box_entry(const accel::BvhNode *n, int s, const RayBox &r, double limit)
+DEV float limit_f32(double limit)
 {
-    double ax = (n->lo[s][0] - r.o.x) * r.inv.x, bx = (n->hi[s][0] - r.o.x) * r.inv.x;
-    double ay = (n->lo[s][1] - r.o.y) * r.inv.y, by = (n->hi[s][1] - r.o.y) * r.inv.y;
-    double az = (n->lo[s][2] - r.o.z) * r.inv.z, bz = (n->hi[s][2] - r.o.z) * r.inv.z;
-    double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), 0.0));
-    double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), limit));
-    return (tn <= tf) ? tn : 1e300;
+    float lf = (float)limit;
+    return lf + fabsf(lf) * 0x1p-22f;   // never below the double it came from
+}
+
+// Conservative entry distance of child c of a 4-wide node, or +inf when the ray misses it within
+// [0, limit].
+DEV float box4_entry(const accel::Bvh4Node *n, int c, const RayBox4 &r, float limitf)
+{
+    const float ax = (n->lo[0][c] - r.olx) * r.ix, bx = (n->hi[0][c] - r.ohx) * r.ix;
+    const float ay = (n->lo[1][c] - r.oly) * r.iy, by = (n->hi[1][c] - r.ohy) * r.iy;
+    const float az = (n->lo[2][c] - r.olz) * r.iz, bz = (n->hi[2][c] - r.ohz) * r.iz;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), limitf));
+    const bool hit = n->child[c] != BVH_NONE && tn * (1.0f - 0x1p-20f) <= tf * (1.0f + 0x1p-20f);
+    return hit ? tn : __builtin_inff();
+}
+
+#define BVH_SORT2(ka, ca, kb, cb)                          \
+    do {                                                   \
+        const bool sw_ = kb < ka;                          \
+        const float tk_ = sw_ ? kb : ka;                   \
+        const int tc_ = sw_ ? cb : ca;                     \
+        kb = sw_ ? ka : kb; cb = sw_ ? ca : cb;            \
+        ka = tk_; ca = tc_;                                \
+    } while (0)
+
+// One step down from inner node `cur`: tests its (up to) four child boxes, continues with the
+// nearest hit child and stacks the others, farthest first (or pops when nothing is hit).
+DEV int bvh4_step(const accel::Bvh4Node *nodes, int cur, const RayBox4 &rb, float limitf, bool ordered, int *stack, int &sp)
+{
+    const accel::Bvh4Node *n = &nodes[cur];
+    float k0 = box4_entry(n, 0, rb, limitf), k1 = box4_entry(n, 1, rb, limitf);
+    float k2 = box4_entry(n, 2, rb, limitf), k3 = box4_entry(n, 3, rb, limitf);
+    int c0 = n->child[0], c1 = n->child[1], c2 = n->child[2], c3 = n->child[3];
+    const float inf = __builtin_inff();
+    if (ordered) {
+        BVH_SORT2(k0, c0, k1, c1);
+        BVH_SORT2(k2, c2, k3, c3);
+        BVH_SORT2(k0, c0, k2, c2);
+        BVH_SORT2(k1, c1, k3, c3);
+        BVH_SORT2(k1, c1, k2, c2);
+        if (k3 < inf) { stack[sp * 256] = c3; ++sp; }
+        if (k2 < inf) { stack[sp * 256] = c2; ++sp; }
+        if (k1 < inf) { stack[sp * 256] = c1; ++sp; }
+        if (k0 < inf) return c0;
+    } else {
+        // any order: hit children go to the stack, the last one pushed is taken straight back
+        if (k0 < inf) { stack[sp * 256] = c0; ++sp; }
+        if (k1 < inf) { stack[sp * 256] = c1; ++sp; }
+        if (k2 < inf) { stack[sp * 256] = c2; ++sp; }
+        if (k3 < inf) { stack[sp * 256] = c3; ++sp; }
+    }
+    if (sp == 0) return BVH_NONE;
+    --sp;
+    return stack[sp * 256];
 }
 
 struct Best {
@@ -396,44 +461,18 @@ struct Best {
     int slot;     // record index | SLOT_SPHERE
 };
 
-// Child codes (accel_build.hpp): >= 0 inner node, BVH_NONE nothing, otherwise a leaf range.
-#define BVH_NONE (-1)
-DEV int leaf_begin(int code) { return (-2 - code) >> 2; }
-DEV int leaf_count(int code) { return ((-2 - code) & 3) + 1; }
-
-// One step down from inner node `cur`: tests both child boxes against [0, limit], pushes the
-// farther hit child and returns the nearer one (or pops when neither is hit).
-DEV int bvh_step(const accel::BvhNode *nodes, int cur, const RayBox &rb, double limit, bool ordered, int *stack, int &sp)
-{
-    const accel::BvhNode *n = &nodes[cur];
-    const int c0 = n->child[0], c1 = n->child[1];
-    const double e0 = (c0 != BVH_NONE) ? box_entry(n, 0, rb, limit) : 1e300;
-    const double e1 = (c1 != BVH_NONE) ? box_entry(n, 1, rb, limit) : 1e300;
-    const bool h0 = e0 < 1e300, h1 = e1 < 1e300;
-    if (h0 && h1) {
-        const bool near0 = !ordered || e0 <= e1;
-        stack[sp * 256] = near0 ? c1 : c0;
-        ++sp;
-        return near0 ? c0 : c1;
-    }
-    if (h0) return c0;
-    if (h1) return c1;
-    if (sp == 0) return BVH_NONE;
-    --sp;
-    return stack[sp * 256];
-}
-
 // Nearest hit over one hierarchy.  TRI selects the leaf record type.  Two phases per round:
 // every lane descends until it holds a leaf (or is done), then the wave tests leaves together.
 template <bool TRI>
-DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox &rb, Best &best, int *stack)
+DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, Best &best, int *stack)
 {
     const double minT = .01, maxT = 10000000000.0;
-    const accel::BvhNode *nodes = TRI ? S.tri_nodes : S.sph_nodes;
+    const accel::Bvh4Node *nodes = TRI ? S.tri_nodes : S.sph_nodes;
     if ((TRI ? S.n_tri_nodes : S.n_sph_nodes) == 0) return;
     int cur = 0, sp = 0;
     while (true) {
-        while (cur >= 0) cur = bvh_step(nodes, cur, rb, best.t * (1.0 + 1e-12) + 1e-12, true, stack, sp);
+        const float limitf = limit_f32(best.t * (1.0 + 1e-12) + 1e-12);
+        while (cur >= 0) cur = bvh4_step(nodes, cur, rb, limitf, true, stack, sp);
         if (cur == BVH_NONE) break;
         const int b = leaf_begin(cur), e = b + leaf_count(cur);
         for (int k = b; k < e; ++k) {
@@ -453,15 +492,15 @@ DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox &rb,
 
 // Any hit in (minT, maxT) by a primitive other than `parent`.
 template <bool TRI>
-DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox &rb, int parent, double maxT, int *stack)
+DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, int parent, double maxT, int *stack)
 {
     const double minT = .01;
-    const accel::BvhNode *nodes = TRI ? S.tri_nodes : S.sph_nodes;
+    const accel::Bvh4Node *nodes = TRI ? S.tri_nodes : S.sph_nodes;
     if ((TRI ? S.n_tri_nodes : S.n_sph_nodes) == 0) return false;
-    const double limit = maxT * (1.0 + 1e-12) + 1e-12;
+    const float limitf = limit_f32(maxT * (1.0 + 1e-12) + 1e-12);
     int cur = 0, sp = 0;
     while (true) {
-        while (cur >= 0) cur = bvh_step(nodes, cur, rb, limit, false, stack, sp);
+        while (cur >= 0) cur = bvh4_step(nodes, cur, rb, limitf, false, stack, sp);
         if (cur == BVH_NONE) break;
         const int b = leaf_begin(cur), e = b + leaf_count(cur);
         for (int k = b; k < e; ++k) {
@@ -792,7 +831,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
                 Best bst;
                 bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1;
                 if (root_gate(P.S, o, d, d2, 10000000000.0)) {
-                    const RayBox rb = make_raybox(o, d);
+                    const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
                     bvh_closest<true>(P.S, o, d, d2, rb, bst, stack);
                     bvh_closest<false>(P.S, o, d, d2, rb, bst, stack);
                 }
@@ -914,7 +953,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_shadow(FrameParams P, Que
                 const double d2 = dot3(rd, rd);
                 occluded = false;
                 if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
-                    const RayBox rb = make_raybox(Pt, rd);
+                    const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
                     occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack) ||
                                bvh_any<false>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack);
                 }
@@ -1264,16 +1303,21 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     std::vector<int32_t> octree_sph_key;
     accel::build(*s, acc, octree_tri, octree_sph_key);
     if ((rc = upload(ctx, octree_tri.data(), octree_tri.size(), &D.tri)) != RT_OK) return rc;
-    if ((rc = upload(ctx, acc.tri_bvh.nodes.data(), acc.tri_bvh.nodes.size(), &D.tri_nodes)) != RT_OK) return rc;
-    if ((rc = upload(ctx, acc.sph_bvh.nodes.data(), acc.sph_bvh.nodes.size(), &D.sph_nodes)) != RT_OK) return rc;
+    if ((rc = upload(ctx, acc.tri_bvh4.nodes.data(), acc.tri_bvh4.nodes.size(), &D.tri_nodes)) != RT_OK) return rc;
+    if ((rc = upload(ctx, acc.sph_bvh4.nodes.data(), acc.sph_bvh4.nodes.size(), &D.sph_nodes)) != RT_OK) return rc;
     if ((rc = upload(ctx, acc.tri.data(), acc.tri.size(), &D.btri)) != RT_OK) return rc;
     if ((rc = upload(ctx, acc.sph.data(), acc.sph.size(), &D.bsph)) != RT_OK) return rc;
     if ((rc = upload(ctx, acc.sph_prim.data(), acc.sph_prim.size(), &D.bsph_prim)) != RT_OK) return rc;
     if ((rc = upload(ctx, acc.sph_key.data(), acc.sph_key.size(), &D.bsph_key)) != RT_OK) return rc;
-    D.n_tri_nodes = (int32_t)acc.tri_bvh.nodes.size();
-    D.n_sph_nodes = (int32_t)acc.sph_bvh.nodes.size();
+    D.n_tri_nodes = (int32_t)acc.tri_bvh4.nodes.size();
+    D.n_sph_nodes = (int32_t)acc.sph_bvh4.nodes.size();
+    {
+        const double bb = acc.tri_bvh4.max_abs_coord > acc.sph_bvh4.max_abs_coord ? acc.tri_bvh4.max_abs_coord
+                                                                                   : acc.sph_bvh4.max_abs_coord;
+        D.bvh_bound = (float)(bb * 1.000001 + 1e-30);
+    }
     ctx->accel_usable = acc.usable;
-    ctx->accel_depth = acc.tri_bvh.max_depth > acc.sph_bvh.max_depth ? acc.tri_bvh.max_depth : acc.sph_bvh.max_depth;
+    ctx->accel_depth = acc.tri_bvh4.max_depth > acc.sph_bvh4.max_depth ? acc.tri_bvh4.max_depth : acc.sph_bvh4.max_depth;
     if ((rc = upload(ctx, s->sph, (size_t)s->n_sph_slots, &D.sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->sph_prim, (size_t)s->n_sph_slots, &D.sph_prim)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->prim_flags, (size_t)s->n_prims, &D.prim_flags)) != RT_OK) return rc;
@@ -1509,8 +1553,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     // transparent sphere exists (checkOccluded3 is then order-free).
     const bool bvh_closest_ok = may_cull && ctx->accel_usable;
     const bool bvh_shadow_ok = bvh_closest_ok && !ctx->any_transparent_sphere;
-    // one pending sibling per level at most, so depth+1 entries always suffice (BVH_STACK is the cap)
-    int stack_entries = ctx->accel_depth + 1;
+    // at most three pending siblings per 4-wide level (BVH_STACK is the cap the builder checks against)
+    int stack_entries = 3 * ctx->accel_depth + 1;
     if (stack_entries > BVH_STACK) stack_entries = BVH_STACK;
     if (stack_entries < 4) stack_entries = 4;
     const size_t lds_closest = bvh_closest_ok ? (size_t)stack_entries * 256 * sizeof(int) : 0;
