@@ -67,14 +67,15 @@ struct alignas(16) RayRec {      // 80 bytes
     uint32_t _pad[2];
 };
 
-struct alignas(16) HitRec {      // 96 bytes
+struct alignas(16) HitRec {      // 128 bytes
     double P[3];                 // impactPos
     double n[3];                 // hr.normal normalised a second time, as computeLocalColor does (Camera.h:382)
+    double nn[3];                // ... and a third time, as computeSpecularComp does (Solid.h:153)
     double v[3];                 // unit vector from the hit point to the ray origin (Solid.h:156)
     double weight;               // factor applied to the local colour
     uint32_t pixel;
     int32_t prim;                // the solid that was hit (never occludes itself)
-    uint32_t _pad[2];
+    double _pad;
 };
 
 struct DevScene {
@@ -374,7 +375,7 @@ DEV int leaf_count(int code) { return ((-2 - code) & 3) + 1; }
 // is left to cover is the rounding of the origin, of the subtractions and of the reciprocal.  The
 // first two are spatial errors of at most 2^-23 (|o| + |plane|): the origin is shifted by `pad`
 // (eight times that) towards each plane's conservative side.  The products carry a relative error
-// of a few 2^-24, covered by the factors (1 -+ 2^-20) in box4_hits.
+// of a few 2^-24, covered by the factors (1 -+ 2^-19) in box4_entry.
 struct RayBox4 {
     float olx, oly, olz;   // origin + pad, used against the `lo` planes
     float ohx, ohy, ohz;   // origin - pad, used against the `hi` planes
@@ -383,8 +384,9 @@ struct RayBox4 {
 DEV float inv_dir(double d)
 {
     // an (almost) axis-parallel ray is nudged for the box test only: 0 * inf would be NaN
-    const double dd = fabs(d) < 1e-30 ? (d < 0 ? -1e-30 : 1e-30) : d;
-    return (float)(1.0 / dd);
+    const float df = (float)d;
+    const float dd = fabsf(df) < 1e-30f ? (d < 0 ? -1e-30f : 1e-30f) : df;
+    return 1.0f / dd;      // conversion + division: a few 2^-24 of relative error, inside the 2^-19 slack
 }
 DEV RayBox4 make_raybox4(d3 o, d3 d, float bound)
 {
@@ -411,7 +413,7 @@ DEV float box4_entry(const accel::Bvh4Node *n, int c, const RayBox4 &r, float li
     const float az = (n->lo[2][c] - r.olz) * r.iz, bz = (n->hi[2][c] - r.ohz) * r.iz;
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), limitf));
-    const bool hit = n->child[c] != BVH_NONE && tn * (1.0f - 0x1p-20f) <= tf * (1.0f + 0x1p-20f);
+    const bool hit = n->child[c] != BVH_NONE && tn * (1.0f - 0x1p-19f) <= tf * (1.0f + 0x1p-19f);
     return hit ? tn : __builtin_inff();
 }
 
@@ -873,7 +875,9 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
                 h->P[0] = Pt.x; h->P[1] = Pt.y; h->P[2] = Pt.z;
                 const d3 n2 = unit3(n);
                 const d3 vv = unit3(sub3(o, Pt));
+                const d3 n3 = unit3(n2);
                 h->n[0] = n2.x; h->n[1] = n2.y; h->n[2] = n2.z;
+                h->nn[0] = n3.x; h->nn[1] = n3.y; h->nn[2] = n3.z;
                 h->v[0] = vv.x; h->v[1] = vv.y; h->v[2] = vv.z;
                 h->weight = wloc;
                 h->pixel = pixel;
@@ -916,8 +920,11 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
     }
 }
 
+#ifndef RT_MIN_WAVES_SHADOW
+#define RT_MIN_WAVES_SHADOW 4
+#endif
 template <bool BVH>
-__global__ __launch_bounds__(256, RT_MIN_WAVES) void k_shadow(FrameParams P, QueueSet Q)
+__global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams P, QueueSet Q)
 {
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
     extern __shared__ int s_stack[];
@@ -978,7 +985,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_shadow(FrameParams P, Que
                 const rt_material m = P.S.materials[P.S.prim_material[hr->prim]];
                 const d3 normal = ld3(hr->n);
                 if (m.Ks > 0) {
-                    d3 nn = unit3(normal);            // third normalisation (Solid.h:153)
+                    d3 nn = ld3(hr->nn);
                     d3 v = ld3(hr->v);
                     d3 lDir = rd;                     // unit3(lpos - Pt), the same value as the shadow ray direction
                     d3 rdir = unit3(add3(neg3(lDir), scale3(2.0 * dot3(lDir, nn), nn)));
@@ -1137,7 +1144,9 @@ struct rt_ctx {
     // frame resources (grow-only)
     double *accum = nullptr; size_t accum_values = 0;
     RayRec *rays[2] = {nullptr, nullptr}; size_t ray_capacity[2] = {0, 0};
-    HitRec *hits = nullptr; size_t hit_capacity = 0;
+    HitRec *hits[4] = {nullptr, nullptr, nullptr, nullptr}; size_t hit_capacity[4] = {0, 0, 0, 0};
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_c[6] = {}, ev_s[6] = {}, ev_batch[2] = {};
     uint32_t *counts = nullptr;
     unsigned long long *totals = nullptr;
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr}; size_t stage_bytes[4] = {0, 0, 0, 0};
@@ -1207,9 +1216,15 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
     ctx->device = device_id;
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (int k = 0; k < 6; ++k) {
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_c[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_s[k], hipEventDisableTiming));
+    }
+    for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_batch[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&ctx->ev_begin));
     HIP_TRY(hipEventCreate(&ctx->ev_end));
-    HIP_TRY(hipMalloc((void **)&ctx->counts, CNT_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->counts, 2 * CNT_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->totals, 16 * sizeof(unsigned long long)));
     if (getenv("RT_DEBUG")) {
         int n = 0;
@@ -1230,11 +1245,15 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream2);
     free_scene(ctx);
     (void)hipFree(ctx->accum);
     (void)hipFree(ctx->rays[0]);
     (void)hipFree(ctx->rays[1]);
-    (void)hipFree(ctx->hits);
+    for (HitRec *h : ctx->hits) (void)hipFree(h);
+    for (int k = 0; k < 6; ++k) { (void)hipEventDestroy(ctx->ev_c[k]); (void)hipEventDestroy(ctx->ev_s[k]); }
+    for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ctx->ev_batch[k]);
+    (void)hipStreamDestroy(ctx->stream2);
     (void)hipFree(ctx->counts);
     (void)hipFree(ctx->totals);
     for (void *p : ctx->stage) (void)hipFree(p);
@@ -1630,24 +1649,42 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             return fail(RT_ERR_INVALID, "rt_render: batch too large for 32-bit queue indices");
         if ((rc = ensure(&ctx->rays[0], &ctx->ray_capacity[0], (size_t)(need_rays[0] ? need_rays[0] : 64))) != RT_OK) return rc;
         if ((rc = ensure(&ctx->rays[1], &ctx->ray_capacity[1], (size_t)(need_rays[1] ? need_rays[1] : 64))) != RT_OK) return rc;
-        if ((rc = ensure(&ctx->hits, &ctx->hit_capacity, (size_t)need_hits)) != RT_OK) return rc;
+        // four hit buffers: [batch parity][generation parity], so that the shadow pass of one
+        // generation (second stream) can run beside the closest-hit pass of the next one
+        for (int k = 0; k < 4; ++k)
+            if ((rc = ensure(&ctx->hits[k], &ctx->hit_capacity[k], (size_t)need_hits)) != RT_OK) return rc;
 
+        // Two streams.  A: counters memset, closest-hit passes C0..C5 of every batch, in order.
+        // B: shadow/shading passes S0..S5 and the batch's counter roll-up.  S_g waits for C_g; C_g+2
+        // waits for S_g (it re-uses S_g's hit buffer); a batch's memset waits for the roll-up of
+        // the batch two before it (same counter block).  Pixel accumulation is atomic, so the
+        // order in which the passes finish does not matter.
+        // Overlap pays when a pass cannot fill the chip by itself (small frames: each pass is one
+        // ray's latency long); big batches already saturate it with one persistent grid, and there
+        // the extra ordering constraints only cost, so they run on one stream.
+        const bool overlap = batch_chunks * 64 <= (1ll << 22);
+        hipStream_t sb = overlap ? ctx->stream2 : st;
         const bool timing = (o->flags & RT_FLAG_TIMING) != 0;
-        for (long long t0 = 0; t0 < n_chunks; t0 += batch_chunks) {
+        long long batch_no = 0;
+        for (long long t0 = 0; t0 < n_chunks; t0 += batch_chunks, ++batch_no) {
             const long long t1 = (t0 + batch_chunks < n_chunks) ? t0 + batch_chunks : n_chunks;
-            HIP_TRY(hipMemsetAsync(ctx->counts, 0, CNT_WORDS * sizeof(uint32_t), st));
+            const int par = (int)(batch_no & 1);
+            uint32_t *counts = ctx->counts + (size_t)par * CNT_WORDS;
+            if (batch_no >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[par], 0));
+            HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
             for (int g = 0; g < 6; ++g) {
                 QueueSet Q{};
                 Q.rays_in = ctx->rays[g & 1];
                 Q.rays_out = ctx->rays[(g + 1) & 1];
-                Q.hits = ctx->hits;
-                Q.counts = ctx->counts;
+                Q.hits = ctx->hits[par * 2 + (g & 1)];
+                Q.counts = counts;
                 Q.in_shard_cap = (uint32_t)ray_cap[g];
                 Q.out_shard_cap = (uint32_t)(g < 5 ? ray_cap[g + 1] : 0);
                 Q.hit_shard_cap = (uint32_t)hit_cap[g];
                 Q.generation = g;
                 Q.chunk_begin = t0;
                 Q.chunk_end = t1;
+                if (g >= 2 && P.S.n_lights > 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_s[g - 2], 0));
                 std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
                 if (timing && !(ev = next_event_pair(ctx->ev_closest, ctx->ev_closest_used)))
                     return fail(RT_ERR_DEVICE, "hipEventCreate failed");
@@ -1662,19 +1699,27 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     else hipLaunchKernelGGL((k_closest<false, false>), dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
                 }
                 if (ev) HIP_TRY(hipEventRecord(ev->second, st));
+                HIP_TRY(hipEventRecord(ctx->ev_c[g], st));
                 if (P.S.n_lights > 0) {
+                    HIP_TRY(hipStreamWaitEvent(sb, ctx->ev_c[g], 0));
                     ev = nullptr;
                     if (timing && !(ev = next_event_pair(ctx->ev_shadow, ctx->ev_shadow_used)))
                         return fail(RT_ERR_DEVICE, "hipEventCreate failed");
-                    if (ev) HIP_TRY(hipEventRecord(ev->first, st));
-                    if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, st, P, Q);
-                    else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
-                    if (ev) HIP_TRY(hipEventRecord(ev->second, st));
+                    if (ev) HIP_TRY(hipEventRecord(ev->first, sb));
+                    if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
+                    else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(256), 0, sb, P, Q);
+                    if (ev) HIP_TRY(hipEventRecord(ev->second, sb));
+                    HIP_TRY(hipEventRecord(ctx->ev_s[g], sb));
                 }
             }
-            hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, ctx->counts, ctx->totals, P.S.n_lights);
+            HIP_TRY(hipStreamWaitEvent(sb, ctx->ev_c[5], 0));
+            hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, sb, counts, ctx->totals, P.S.n_lights);
+            HIP_TRY(hipEventRecord(ctx->ev_batch[par], sb));
             ctx->pending_batches++;
         }
+        // the frame is complete when the second stream has drained
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[0], 0));
+        if (batch_no >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[1], 0));
         HIP_TRY(hipGetLastError());
         {
             const long long n_values = (long long)n_pixels * 3;
@@ -1749,7 +1794,7 @@ extern "C" int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
 {
     int rc = enqueue_frame(ctx, cam, opts, out, out && out->on_device);
     if (rc != RT_OK) {
-        if (ctx) { (void)hipStreamSynchronize(ctx->stream); ctx->pending = false; }
+        if (ctx) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); ctx->pending = false; }
         return rc;
     }
     return rt_sync(ctx, stats);
