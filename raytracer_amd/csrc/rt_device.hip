@@ -75,7 +75,7 @@ struct alignas(16) HitRec {      // 128 bytes
     double weight;               // factor applied to the local colour
     uint32_t pixel;
     int32_t prim;                // the solid that was hit (never occludes itself)
-    double _pad;
+    int32_t light, cam;          // only in the deferred light-camera queue: light index, camera index
 };
 
 struct DevScene {
@@ -132,13 +132,15 @@ struct FrameParams {
 #define N_SHARDS 64
 #define CNT_RAYS(g) ((g) * N_SHARDS)             // g = 0..6
 #define CNT_HITS(g) ((7 + (g)) * N_SHARDS)       // g = 0..5
-#define CNT_OVERFLOW (13 * N_SHARDS)
-#define CNT_WORDS (13 * N_SHARDS + 16)
+#define CNT_DEFER(g) ((13 + (g)) * N_SHARDS)     // g = 0..5: deferred light-camera evaluations
+#define CNT_OVERFLOW (19 * N_SHARDS)
+#define CNT_WORDS (19 * N_SHARDS + 16)
 
 struct QueueSet {
     RayRec *rays_in;
     RayRec *rays_out;
     HitRec *hits;
+    HitRec *deferred;            // light-camera evaluations postponed by the shadow pass (same shard size as hits)
     uint32_t *counts;
     uint32_t in_shard_cap, out_shard_cap, hit_shard_cap;   // records per shard
     int32_t generation;
@@ -599,6 +601,9 @@ DEV double lc_calc_intensity(const DevLightCam &cam, d3 pos)
     double maxDist = cam.spw * (dist / sphereDistToLight);
     maxDist *= smoothingFactor;
     double total = 0;
+    // sqrt is monotonic and correctly rounded: |v| < maxDist is decided on the squared length
+    // unless it lies within a few ulps of maxDist^2, where the reference's own comparison runs
+    const double m2 = maxDist * maxDist, m2_lo = m2 * (1.0 - 0x1p-48), m2_hi = m2 * (1.0 + 0x1p-48);
     if (cam.n_nodes > 0) {
         // depth-first, children 0..7.  Descent stops at nodes smaller than 2*maxDist, so at most
         // ~7 pending siblings per level over a dozen levels are ever stacked.
@@ -610,8 +615,11 @@ DEV double lc_calc_intensity(const DevLightCam &cam, d3 pos)
             if (r->size < maxDist * 2 || r->leaf) {
                 for (int k = r->begin; k < r->end; ++k) {
                     const lightcam::Point *q = &cam.points[k];
-                    double dd = norm3(sub3(mk3(q->x, q->y, q->z), pos));
-                    if (dd < maxDist) total += q->w;
+                    const d3 dv = sub3(mk3(q->x, q->y, q->z), pos);
+                    const double s2 = dot3(dv, dv);
+                    bool inside = s2 < m2_lo;
+                    if (!inside && !(s2 > m2_hi)) inside = sqrt(s2) < maxDist;
+                    if (inside) total += q->w;
                 }
             } else {
                 const double epsilon = maxDist * 0.1;
@@ -920,6 +928,105 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
     }
 }
 
+// The same query for a whole wave at once (every lane calls it; `active` lanes hold a query).
+// Each lane walks its own octree path, but a terminal node with many points is postponed and then
+// scanned by all 64 lanes together: the caustic foci put thousands of impacts into single cells,
+// and one lane scanning them alone would hold up its whole wave.
+DEV double lc_calc_intensity_wave(const DevLightCam *table, int cam_index, d3 pos, bool active)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const DevLightCam cam = table[active ? cam_index : 0];
+    const d3 lp = ld3(cam.light_pos), spos = ld3(cam.sphere_pos);
+    const double dist = norm3(sub3(pos, lp));
+    const double sphereDistToLight = norm3(sub3(lp, spos));
+    double maxDist = cam.spw * (dist / sphereDistToLight);
+    maxDist *= 1.5;
+    const double m2 = maxDist * maxDist, m2_lo = m2 * (1.0 - 0x1p-48), m2_hi = m2 * (1.0 + 0x1p-48);
+    double total = 0;
+    int stack[192];
+    int sp_ = 0;
+    if (active && cam.n_nodes > 0) stack[sp_++] = 0;
+    int pend_b = 0, pend_e = 0;
+    while (true) {
+        bool pending = false;
+        while (sp_ > 0 && !pending) {
+            const lightcam::Node *r = &cam.nodes[stack[--sp_]];
+            if (r->size < maxDist * 2 || r->leaf) {
+                if (r->end - r->begin > 24) {
+                    pend_b = r->begin; pend_e = r->end; pending = true;
+                } else {
+                    for (int k = r->begin; k < r->end; ++k) {
+                        const lightcam::Point *q = &cam.points[k];
+                        const d3 dv = sub3(mk3(q->x, q->y, q->z), pos);
+                        const double s2 = dot3(dv, dv);
+                        bool inside = s2 < m2_lo;
+                        if (!inside && !(s2 > m2_hi)) inside = sqrt(s2) < maxDist;
+                        if (inside) total += q->w;
+                    }
+                }
+            } else {
+                const double epsilon = maxDist * 0.1;
+                if (norm3(sub3(pos, mk3(r->cx, r->cy, r->cz))) < (r->size + epsilon)) {
+                    for (int c = 7; c >= 0; --c)
+                        if (r->child[c] >= 0 && sp_ < 192) stack[sp_++] = r->child[c];
+                }
+            }
+        }
+        unsigned long long mask = __ballot(pending);
+        if (mask == 0) break;     // every lane has emptied its stack
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int b = __shfl(pend_b, l), e = __shfl(pend_e, l);
+            const int ci = __shfl(cam_index, l);
+            const lightcam::Point *pts = table[ci].points;
+            const d3 qp = mk3(__shfl(pos.x, l), __shfl(pos.y, l), __shfl(pos.z, l));
+            const double qmax = __shfl(maxDist, l), qlo = __shfl(m2_lo, l), qhi = __shfl(m2_hi, l);
+            double part = 0;
+            for (int k = b + lane; k < e; k += 64) {
+                const lightcam::Point *q = &pts[k];
+                const d3 dv = sub3(mk3(q->x, q->y, q->z), qp);
+                const double s2 = dot3(dv, dv);
+                bool inside = s2 < qlo;
+                if (!inside && !(s2 > qhi)) inside = sqrt(s2) < qmax;
+                if (inside) part += q->w;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == l) total += part;
+        }
+    }
+    const double expected = (maxDist * maxDist) / (cam.spw * cam.spw);
+    return total / expected;
+}
+
+// Diffuse + specular terms of one light at one hit (Solid.h:128-172), scaled by `kfac`
+// (Camera.h:465-476).  `rd` is the unit vector from the hit point to the light.
+DEV d3 phong_terms(const DevScene &S, const HitRec *hr, const rt_light *lt, d3 rd, double kfac)
+{
+    const rt_material m = S.materials[S.prim_material[hr->prim]];
+    const d3 normal = ld3(hr->n);
+    d3 local = mk3(0, 0, 0);
+    if (m.Ks > 0) {
+        d3 nn = ld3(hr->nn);
+        d3 v = ld3(hr->v);
+        d3 rdir = unit3(add3(neg3(rd), scale3(2.0 * dot3(rd, nn), nn)));
+        double a = dot3(rdir, v);
+        double pw = pow((a < 0.0) ? 0.0 : a, m.Shine);
+        double ik = lt->intensity * m.Ks;
+        d3 comp = mk3((ik * lt->color[0]) * pw, (ik * lt->color[1]) * pw, (ik * lt->color[2]) * pw);
+        local = add3(local, scale3(kfac, comp));
+    }
+    {
+        double a = dot3(rd, normal);
+        double dm = (a < 0.0) ? 0.0 : a;
+        double ik = lt->intensity * m.Kd;
+        d3 comp = mk3((ik * m.r) * dm, (ik * m.g) * dm, (ik * m.b) * dm);
+        local = add3(local, scale3(kfac, comp));
+    }
+    return local;
+}
+
 #ifndef RT_MIN_WAVES_SHADOW
 #define RT_MIN_WAVES_SHADOW 4
 #endif
@@ -947,6 +1054,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
         const d3 lpos = ld3(lt->pos);
         const uint32_t pixel = hr->pixel;
         bool lit = false;
+        int defer_cam = -1;
         d3 local = mk3(0, 0, 0);
         if (active) {
             const d3 toL = sub3(lpos, Pt);
@@ -967,44 +1075,60 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
             } else {
                 occluded = trace_shadow(P.S, Pt, rd, hr->prim, maxT, cull, &only, &closest);
             }
-            double kfac = .999999;
             if (occluded && only) {
                 // shadowed by transparent spheres only: the light camera of (that sphere, this light)
-                // decides how much light arrives (Camera.h:406-451)
+                // decides how much light arrives (Camera.h:406-451); evaluated in k_lightcam
                 if (P.lc_mask) P.lc_mask[pixel] = 1;
                 if (P.S.lc_table && closest >= 0) {
                     const int rank = P.S.prim_lc_rank[closest];
-                    if (rank >= 0) {
-                        kfac = lc_calc_intensity(P.S.lc_table[rank * P.S.n_lights + li], Pt);
-                        if (kfac > .01) occluded = false;
-                    }
+                    if (rank >= 0) defer_cam = rank * P.S.n_lights + li;
                 }
             }
             lit = !occluded;
-            if (lit) {
-                const rt_material m = P.S.materials[P.S.prim_material[hr->prim]];
-                const d3 normal = ld3(hr->n);
-                if (m.Ks > 0) {
-                    d3 nn = ld3(hr->nn);
-                    d3 v = ld3(hr->v);
-                    d3 lDir = rd;                     // unit3(lpos - Pt), the same value as the shadow ray direction
-                    d3 rdir = unit3(add3(neg3(lDir), scale3(2.0 * dot3(lDir, nn), nn)));
-                    double a = dot3(rdir, v);
-                    double pw = pow((a < 0.0) ? 0.0 : a, m.Shine);
-                    double ik = lt->intensity * m.Ks;
-                    d3 comp = mk3((ik * lt->color[0]) * pw, (ik * lt->color[1]) * pw, (ik * lt->color[2]) * pw);
-                    local = add3(local, scale3(kfac, comp));
-                }
-                {
-                    double a = dot3(rd, normal);
-                    double dm = (a < 0.0) ? 0.0 : a;
-                    double ik = lt->intensity * m.Kd;
-                    d3 comp = mk3((ik * m.r) * dm, (ik * m.g) * dm, (ik * m.b) * dm);
-                    local = add3(local, scale3(kfac, comp));
-                }
+            if (lit) local = phong_terms(P.S, hr, lt, rd, .999999);
+        }
+        if (!BVH && P.S.lc_table) {
+            bool ok;
+            const bool want = defer_cam >= 0;
+            const uint32_t slot = wave_reserve(want, &Q.counts[CNT_DEFER(Q.generation)], Q.hit_shard_cap, &Q.counts[CNT_OVERFLOW + 1], &ok);
+            if (ok) {
+                HitRec *dr = &Q.deferred[slot];
+                *dr = *hr;
+                dr->light = li;
+                dr->cam = defer_cam;
+            } else if (want) {   // queue full: evaluate here
+                const double kfac = lc_calc_intensity(P.S.lc_table[defer_cam], Pt);
+                if (kfac > .01) { lit = true; local = phong_terms(P.S, hr, lt, unit3(sub3(lpos, Pt)), kfac); }
             }
         }
         accum_add_runs(P.accum, active, lit, pixel, hr->weight, local);
+    }
+}
+
+// Deferred light-camera evaluations of one generation: density query, then the same shading as a
+// lit point with the query result as the factor (Camera.h:444-476).
+__global__ __launch_bounds__(256) void k_lightcam(FrameParams P, QueueSet Q)
+{
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const ShardMap smap = shard_map(&Q.counts[CNT_DEFER(Q.generation)], Q.hit_shard_cap, 1u);
+    for (long long chunk = wave; chunk < (long long)smap.total; chunk += n_waves) {
+        int shard;
+        const int item = shard_locate(smap, (uint32_t)chunk, &shard);
+        const bool active = item >= 0;
+        const HitRec *hr = &Q.deferred[(size_t)shard * Q.hit_shard_cap + (active ? (uint32_t)item : 0u)];
+        bool lit = false;
+        d3 local = mk3(0, 0, 0);
+        const d3 Pt = ld3(hr->P);
+        const double kfac = lc_calc_intensity_wave(P.S.lc_table, active ? hr->cam : 0, Pt, active);
+        if (active) {
+            const rt_light *lt = &P.S.lights[hr->light];
+            if (kfac > .01) {
+                lit = true;
+                local = phong_terms(P.S, hr, lt, unit3(sub3(ld3(lt->pos), Pt)), kfac);
+            }
+        }
+        accum_add_runs(P.accum, active, lit, hr->pixel, hr->weight, local);
     }
 }
 
@@ -1145,6 +1269,7 @@ struct rt_ctx {
     double *accum = nullptr; size_t accum_values = 0;
     RayRec *rays[2] = {nullptr, nullptr}; size_t ray_capacity[2] = {0, 0};
     HitRec *hits[4] = {nullptr, nullptr, nullptr, nullptr}; size_t hit_capacity[4] = {0, 0, 0, 0};
+    HitRec *deferred = nullptr; size_t deferred_capacity = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_c[6] = {}, ev_s[6] = {}, ev_batch[2] = {};
     uint32_t *counts = nullptr;
@@ -1251,6 +1376,7 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     (void)hipFree(ctx->rays[0]);
     (void)hipFree(ctx->rays[1]);
     for (HitRec *h : ctx->hits) (void)hipFree(h);
+    (void)hipFree(ctx->deferred);
     for (int k = 0; k < 6; ++k) { (void)hipEventDestroy(ctx->ev_c[k]); (void)hipEventDestroy(ctx->ev_s[k]); }
     for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ctx->ev_batch[k]);
     (void)hipStreamDestroy(ctx->stream2);
@@ -1653,6 +1779,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         // generation (second stream) can run beside the closest-hit pass of the next one
         for (int k = 0; k < 4; ++k)
             if ((rc = ensure(&ctx->hits[k], &ctx->hit_capacity[k], (size_t)need_hits)) != RT_OK) return rc;
+        const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
+        if (use_lightcam && (rc = ensure(&ctx->deferred, &ctx->deferred_capacity, (size_t)need_hits)) != RT_OK) return rc;
 
         // Two streams.  A: counters memset, closest-hit passes C0..C5 of every batch, in order.
         // B: shadow/shading passes S0..S5 and the batch's counter roll-up.  S_g waits for C_g; C_g+2
@@ -1677,6 +1805,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.rays_in = ctx->rays[g & 1];
                 Q.rays_out = ctx->rays[(g + 1) & 1];
                 Q.hits = ctx->hits[par * 2 + (g & 1)];
+                Q.deferred = ctx->deferred;
                 Q.counts = counts;
                 Q.in_shard_cap = (uint32_t)ray_cap[g];
                 Q.out_shard_cap = (uint32_t)(g < 5 ? ray_cap[g + 1] : 0);
@@ -1708,6 +1837,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     if (ev) HIP_TRY(hipEventRecord(ev->first, sb));
                     if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
                     else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(256), 0, sb, P, Q);
+                    if (use_lightcam) hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks), dim3(256), 0, sb, P, Q);
                     if (ev) HIP_TRY(hipEventRecord(ev->second, sb));
                     HIP_TRY(hipEventRecord(ctx->ev_s[g], sb));
                 }
