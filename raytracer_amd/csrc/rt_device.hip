@@ -1404,13 +1404,13 @@ extern "C" int rt_set_batch(rt_ctx *ctx, int64_t primaries)
 static int validate_scene(const rt_scene_desc *s)
 {
     if (!s->nodes || s->n_nodes <= 0) return fail(RT_ERR_INVALID, "scene: no nodes");
-    if (s->n_tri_slots < 0 || s->n_sph_slots < 0 || s->n_prims < 0 || s->n_materials <= 0 || s->n_lights < 0)
+    if (s->n_tri_slots < 0 || s->n_sph_slots < 0 || s->n_prims < 0 || s->n_materials < 0 || s->n_lights < 0)
         return fail(RT_ERR_INVALID, "scene: negative count");
     if ((s->n_tri_slots && !s->tri) || (s->n_sph_slots && (!s->sph || !s->sph_prim)))
         return fail(RT_ERR_INVALID, "scene: missing primitive records");
     if (s->n_prims && (!s->prim_flags || !s->prim_material || !s->prim_normals))
         return fail(RT_ERR_INVALID, "scene: missing per-primitive arrays");
-    if (!s->materials || (s->n_lights && !s->lights)) return fail(RT_ERR_INVALID, "scene: missing materials or lights");
+    if ((s->n_materials && !s->materials) || (s->n_lights && !s->lights)) return fail(RT_ERR_INVALID, "scene: missing materials or lights");
     for (int32_t i = 0; i < s->n_nodes; ++i) {
         const rt_node &n = s->nodes[i];
         if (n.skip <= i || n.skip > s->n_nodes) return fail(RT_ERR_INVALID, "scene: node skip link out of order");
