@@ -37,6 +37,9 @@ def load():
     lib.orc_render.restype = C.c_int
     lib.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int,
                                dp, ip, dp, C.POINTER(C.c_ubyte), C.POINTER(C.c_uint64)]
+    lib.orc_render_rows.restype = C.c_int
+    lib.orc_render_rows.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, ip, C.c_int, C.c_uint32, C.c_int,
+                                    dp, ip, dp, C.POINTER(C.c_ubyte), C.POINTER(C.c_uint64)]
     lib.orc_write_ppm.argtypes = [dp, C.c_int, C.c_int, C.c_char_p]
     lib.orc_get_solid.argtypes = [C.c_void_p, C.c_int, ip, dp, dp, ip, dp]
     lib.orc_get_camera.argtypes = [C.c_void_p, dp]
@@ -95,8 +98,8 @@ class OracleScene:
         self.lightcam_samples = n
 
     def render(self, num_samples=1, aperture=0.0, threads=8, row0=0, row1=None, seed=0, flags=0,
-               want_hits=True, want_mask=True):
-        """Full-frame buffers; only rows [row0,row1) are written."""
+               want_hits=True, want_mask=True, want_u8=True, rows=None):
+        """Full-frame buffers; only rows [row0,row1), or the rows listed in `rows`, are written."""
         if row1 is None:
             row1 = self.resy
         px = np.zeros((self.resy, self.resx, 3), dtype=np.float64)
@@ -104,13 +107,17 @@ class OracleScene:
         ht = np.zeros((self.resy, self.resx), dtype=np.float64) if want_hits else None
         mask = np.zeros((self.resy, self.resx), dtype=np.uint8) if want_mask else None
         ctr = (C.c_uint64 * 7)()
-        rc = load().orc_render(self._h, num_samples, aperture, threads, row0, row1, seed, flags, _dp(px),
-                               hit.ctypes.data_as(C.POINTER(C.c_int)) if want_hits else None,
-                               _dp(ht) if want_hits else None,
-                               mask.ctypes.data_as(C.POINTER(C.c_ubyte)) if want_mask else None, ctr)
+        outs = (_dp(px), hit.ctypes.data_as(C.POINTER(C.c_int)) if want_hits else None, _dp(ht) if want_hits else None,
+                mask.ctypes.data_as(C.POINTER(C.c_ubyte)) if want_mask else None, ctr)
+        if rows is not None:
+            rl = np.ascontiguousarray(rows, dtype=np.int32)
+            rc = load().orc_render_rows(self._h, num_samples, aperture, threads, rl.ctypes.data_as(C.POINTER(C.c_int)),
+                                        len(rl), seed, flags, *outs)
+        else:
+            rc = load().orc_render(self._h, num_samples, aperture, threads, row0, row1, seed, flags, *outs)
         if rc != 0:
             raise RuntimeError("oracle render failed")
-        return {"rgb_f64": px, "rgb_u8": px.astype(np.int32).astype(np.uint8), "hit_id": hit, "hit_t": ht,
+        return {"rgb_f64": px, "rgb_u8": px.astype(np.int32).astype(np.uint8) if want_u8 else None, "hit_id": hit, "hit_t": ht,
                 "lightcam_mask": mask, "counters": dict(zip(COUNTER_NAMES, [int(x) for x in ctr]))}
 
     def solid(self, i):

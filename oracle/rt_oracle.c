@@ -1072,6 +1072,7 @@ typedef struct {
     Scene *sc;
     Camera cam;
     int flags, tid, nthreads, row0, row1;
+    const int *rows;           /* optional explicit row list: then row0..row1 index into it */
     uint32_t seed;
     double *pixels;
     int *hit_ids;
@@ -1091,7 +1092,8 @@ static void *render_rows(void *arg)
     cx.flags = jb->flags;
     cx.lc_mask = jb->lc_mask;
     int resx = jb->cam.resx;
-    for (int i = jb->row0 + jb->tid; i < jb->row1; i += jb->nthreads)
+    for (int k = jb->row0 + jb->tid; k < jb->row1; k += jb->nthreads) {
+        const int i = jb->rows ? jb->rows[k] : k;
         for (int j = 0; j < resx; j++) {
             size_t px = (size_t)i * (size_t)resx + (size_t)j;
             cx.cur_pixel = (int)px;
@@ -1104,6 +1106,7 @@ static void *render_rows(void *arg)
             if (jb->hit_ids) jb->hit_ids[px] = hid;
             if (jb->hit_t) jb->hit_t[px] = ht;
         }
+    }
     jb->ctr = cx.ctr;
     return NULL;
 }
@@ -1149,11 +1152,10 @@ void orc_set_lightcam_samples(Scene *s, int n) { s->lightCamSamples = n; }
  * to integers) with `nthreads` row-interleaved threads.  counters[7] receives:
  * closest rays, shadow rays, node tests (closest), prim tests (closest), node tests
  * (shadow), prim tests (shadow), light-camera queries.  hit_ids / hit_t / lc_mask may be NULL. */
-int orc_render(Scene *s, int numSamples, double aperture, int nthreads, int row0, int row1, uint32_t seed, int flags,
-               double *pixels, int *hit_ids, double *hit_t, unsigned char *lc_mask, uint64_t *counters)
+static int render_job(Scene *s, int numSamples, double aperture, int nthreads, int row0, int row1, const int *rows,
+                      uint32_t seed, int flags, double *pixels, int *hit_ids, double *hit_t, unsigned char *lc_mask,
+                      uint64_t *counters)
 {
-    if (!s || s->resx <= 0 || s->resy <= 0 || nthreads < 1) return -1;
-    if (row1 > s->resy) row1 = s->resy;
     Camera cam;
     memset(&cam, 0, sizeof cam);
     camera_setup(&cam, s->from, s->at, s->up, s->bg, s->angle, s->resx, s->resy, 0);
@@ -1163,7 +1165,7 @@ int orc_render(Scene *s, int numSamples, double aperture, int nthreads, int row0
     pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
     for (int t = 0; t < nthreads; t++) {
         jobs[t].sc = s; jobs[t].cam = cam; jobs[t].flags = flags; jobs[t].tid = t; jobs[t].nthreads = nthreads;
-        jobs[t].row0 = row0; jobs[t].row1 = row1; jobs[t].seed = seed; jobs[t].pixels = pixels;
+        jobs[t].row0 = row0; jobs[t].row1 = row1; jobs[t].rows = rows; jobs[t].seed = seed; jobs[t].pixels = pixels;
         jobs[t].hit_ids = hit_ids; jobs[t].hit_t = hit_t; jobs[t].lc_mask = lc_mask;
         pthread_create(&th[t], NULL, render_rows, &jobs[t]);
     }
@@ -1187,6 +1189,27 @@ int orc_render(Scene *s, int numSamples, double aperture, int nthreads, int row0
     free(jobs);
     free(th);
     return 0;
+}
+
+int orc_render(Scene *s, int numSamples, double aperture, int nthreads, int row0, int row1, uint32_t seed, int flags,
+               double *pixels, int *hit_ids, double *hit_t, unsigned char *lc_mask, uint64_t *counters)
+{
+    if (!s || s->resx <= 0 || s->resy <= 0 || nthreads < 1) return -1;
+    if (row1 > s->resy) row1 = s->resy;
+    if (row0 < 0) row0 = 0;
+    return render_job(s, numSamples, aperture, nthreads, row0, row1, NULL, seed, flags, pixels, hit_ids, hit_t, lc_mask,
+                      counters);
+}
+
+/* Same, for an explicit list of rows (threads interleave over the list), e.g. a sample of a large frame. */
+int orc_render_rows(Scene *s, int numSamples, double aperture, int nthreads, const int *rows, int n_rows, uint32_t seed,
+                    int flags, double *pixels, int *hit_ids, double *hit_t, unsigned char *lc_mask, uint64_t *counters)
+{
+    if (!s || s->resx <= 0 || s->resy <= 0 || nthreads < 1 || !rows || n_rows < 0) return -1;
+    for (int k = 0; k < n_rows; k++)
+        if (rows[k] < 0 || rows[k] >= s->resy) return -1;
+    return render_job(s, numSamples, aperture, nthreads, 0, n_rows, rows, seed, flags, pixels, hit_ids, hit_t, lc_mask,
+                      counters);
 }
 
 /* writeImage, Driver.cpp:712-733: (int) truncation, binary P6 */
