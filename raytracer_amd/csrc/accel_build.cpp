@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -47,7 +48,7 @@ struct Box {
     }
 };
 
-constexpr int kLeafMax = 4;
+int kLeafMax = 2;               // 1..4 (the leaf code keeps count-1 in two bits); 2 measured best: box tests are cheap, FP64 records are not
 constexpr int kBins = 16;
 constexpr int kSahDepth = 14;   // below this depth splits are medians, which bounds the tree height
 
@@ -264,12 +265,15 @@ int32_t collapse_node(const Bvh &b2, int32_t idx2, Bvh4 &out, int depth)
     std::memset(&nd, 0, sizeof nd);
     for (int c = 0; c < 4; ++c) {
         nd.child[c] = -1;
-        for (int k = 0; k < 3; ++k) { nd.lo[k][c] = 1.0f; nd.hi[k][c] = -1.0f; }
+        for (int k = 0; k < 3; ++k) {
+            nd.plane[k][0][c] = std::numeric_limits<float>::max();
+            nd.plane[k][1][c] = -std::numeric_limits<float>::max();
+        }
     }
     for (size_t c = 0; c < kids.size(); ++c) {
         for (int k = 0; k < 3; ++k) {
-            nd.lo[k][c] = round_down(kids[c].lo[k]);
-            nd.hi[k][c] = round_up(kids[c].hi[k]);
+            nd.plane[k][0][c] = round_down(kids[c].lo[k]);
+            nd.plane[k][1][c] = round_up(kids[c].hi[k]);
             out.max_abs_coord = std::max({out.max_abs_coord, std::fabs(kids[c].lo[k]), std::fabs(kids[c].hi[k])});
         }
         nd.child[c] = kids[c].code;   // leaf codes pass through; inner codes are rewritten below
@@ -283,11 +287,38 @@ int32_t collapse_node(const Bvh &b2, int32_t idx2, Bvh4 &out, int depth)
     return me;
 }
 
+// Renumbers the nodes breadth-first, so that the first K nodes are the K nodes nearest the root:
+// the device keeps a prefix of the array in on-chip memory, and the top of the tree is what
+// every ray visits.
+void breadth_first(Bvh4 &t)
+{
+    const size_t n = t.nodes.size();
+    std::vector<int32_t> order;           // order[new] = old
+    order.reserve(n);
+    std::vector<int32_t> new_of(n, -1);
+    order.push_back(0);
+    for (size_t head = 0; head < order.size(); ++head) {
+        const Bvh4Node &nd = t.nodes[order[head]];
+        for (int c = 0; c < 4; ++c)
+            if (nd.child[c] >= 0) order.push_back(nd.child[c]);
+    }
+    for (size_t i = 0; i < order.size(); ++i) new_of[order[i]] = static_cast<int32_t>(i);
+    std::vector<Bvh4Node> out(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        Bvh4Node nd = t.nodes[order[i]];
+        for (int c = 0; c < 4; ++c)
+            if (nd.child[c] >= 0) nd.child[c] = new_of[nd.child[c]];
+        out[i] = nd;
+    }
+    t.nodes.swap(out);
+}
+
 void collapse(const Bvh &b2, Bvh4 &out)
 {
     out = Bvh4();
     if (b2.nodes.empty()) return;
     collapse_node(b2, 0, out, 1);
+    breadth_first(out);
 }
 
 }  // namespace
@@ -295,6 +326,10 @@ void collapse(const Bvh &b2, Bvh4 &out)
 void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_tri, std::vector<int32_t> &octree_sph_key)
 {
     out = Accel();
+    if (const char *e = std::getenv("RT_LEAF_MAX")) {      // experiments only
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 4) kLeafMax = v;
+    }
     octree_tri.assign(d.tri, d.tri + d.n_tri_slots);
     octree_sph_key.assign(static_cast<size_t>(d.n_sph_slots), 0);
 

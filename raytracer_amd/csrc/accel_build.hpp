@@ -29,11 +29,13 @@ struct Bvh {
 };
 
 // The device walks a 4-wide form of the same tree: every node holds the boxes of up to four
-// children as single-precision bounds rounded OUTWARD (lo down, hi up), child-major per axis,
-// so one 128-byte record answers two levels of the binary tree.  Codes as in BvhNode::child.
+// children as single-precision bounds rounded OUTWARD (lo down, hi up), so one 128-byte record
+// answers two levels of the binary tree.  plane[axis][0] holds the four children's lower bounds
+// on that axis, plane[axis][1] the upper bounds: a ray picks its near and far planes of an axis
+// by the sign of its direction with one address bit (byte offset 32*axis + 16*side).  An unused
+// child slot has an inverted box and code -1.  Codes as in BvhNode::child.
 struct Bvh4Node {
-    float lo[3][4];
-    float hi[3][4];
+    float plane[3][2][4];
     int32_t child[4];
     int32_t _pad[4];
 };

@@ -98,6 +98,8 @@ struct DevScene {
     const uint32_t *bsph_prim;
     const int32_t *bsph_key;
     int32_t n_tri_nodes, n_sph_nodes;
+    int32_t tri_cached, sph_cached;       // the first so many nodes of each hierarchy are copied into LDS by every block
+    int32_t lds_cache_word;               // first LDS word of the node cache (after the traversal stacks)
     float bvh_bound;                      // largest |coordinate| of any hierarchy box
     // light cameras (LightCam.h): one per (transparent sphere, light) pair, index rank*n_lights+light
     const int32_t *prim_lc_rank;          // per primitive: rank among transparent spheres, or -1
@@ -213,16 +215,37 @@ DEV double tri_test(const rt_tri_rec *tr, d3 o, d3 d, double minT, double maxT, 
     return t;
 }
 
+// Operands of one triangle test, fetched as five 16-byte loads (the first 80 bytes of the record:
+// v0, ab, ac, primitive id, tie key).  The memory pipeline spends the same time on a one-word load
+// of a wave as on a four-word one, so the number of load instructions is what counts.
+struct TriOps {
+    d3 v0, ab, ac;
+    int prim, key;
+};
+DEV TriOps load_tri(const rt_tri_rec *tr)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const __attribute__((address_space(1))) v2d *p = (const __attribute__((address_space(1))) v2d *)tr;
+    const v2d a = p[0], b = p[1], c = p[2], e = p[3], f = p[4];
+    TriOps t;
+    t.v0 = mk3(a.x, a.y, b.x);
+    t.ab = mk3(b.y, c.x, c.y);
+    t.ac = mk3(e.x, e.y, f.x);
+    t.prim = __double2loint(f.y);
+    t.key = __double2hiint(f.y);
+    return t;
+}
+
 // The same test with its rejections decided before any division.  The four determinants are
 // built from shared 2x2 minors in the reference's association, so detA, X, Y, Z are bit-identical
 // to det3(); a miss is declared early only when the quotient the reference would form is beyond
 // its threshold by more than the rounding of one division (factor 1 +- 2^-40), otherwise the exact
 // sequence above runs.  `tcut` <= maxT: a hit farther than tcut may be reported as maxT (it
 // cannot replace the current nearest hit, and for shadow queries tcut == maxT).
-DEV double tri_test_fast(const rt_tri_rec *tr, d3 o, d3 d, double minT, double maxT, double tcut)
+DEV double tri_test_fast(const TriOps &tr, d3 o, d3 d, double minT, double maxT, double tcut)
 {
-    const d3 v0 = ld3(tr->v0), ab = ld3(tr->ab), ac = ld3(tr->ac);
-    const double m3 = tr->_pad1[0];                 // ab.y*ac.z - ac.y*ab.z, filled at upload
+    const d3 v0 = tr.v0, ab = tr.ab, ac = tr.ac;
+    const double m3 = ab.y * ac.z - ac.y * ab.z;
     const d3 ae = sub3(v0, o);
     const double m1 = ac.y * d.z - d.y * ac.z;
     const double m2 = d.y * ab.z - ab.y * d.z;
@@ -300,7 +323,7 @@ DEV void trace_closest(const DevScene &S, d3 o, d3 d, bool cull, double minT, do
         }
         if (tcur >= tend && scur >= send) break;
         while (tcur < tend) {
-            double t = tri_test_fast(&S.tri[tcur], o, d, minT, maxT, best_t);
+            double t = tri_test_fast(load_tri(&S.tri[tcur]), o, d, minT, maxT, best_t);
             if (t < best_t) { best_t = t; best = tcur; }
             ++tcur;
         }
@@ -338,11 +361,11 @@ DEV bool trace_shadow(const DevScene &S, d3 o, d3 d, int parent, double maxT, bo
         double furthest = minT;
         const int tb = nd->tri_begin, te = tb + nd->tri_count;
         for (int s = tb; s < te; ++s) {
-            const rt_tri_rec *tr = &S.tri[s];
-            if (tr->prim == parent) continue;
+            const TriOps tr = load_tri(&S.tri[s]);
+            if (tr.prim == parent) continue;
             double t = tri_test_fast(tr, o, d, minT, maxT, maxT);
             if (t < maxT) {   // a triangle always ends the query (Octree.h:1241-1251)
-                if (t > furthest) *closest = tr->prim;
+                if (t > furthest) *closest = tr.prim;
                 *only_transparent = false;
                 return true;
             }
@@ -365,6 +388,35 @@ DEV bool trace_shadow(const DevScene &S, d3 o, d3 d, int parent, double maxT, bo
     return seen;
 }
 
+// ------------------------------------------------------------------ traversal statistics (diagnostic builds only)
+// With -DRT_COUNT the hierarchy walks count, per kernel class, what every lane did and how many
+// loop trips its wave made for it; rt_debug_counters() reads the totals.  Normal builds carry none of it.
+struct WalkCount {
+#ifdef RT_COUNT
+    unsigned long long rays, lane_nodes, wave_nodes, lane_prims, wave_prims, lane_leaves, wave_rounds;
+#endif
+};
+#ifdef RT_COUNT
+__device__ unsigned long long g_walk_counts[32];
+#define WC_ADD(cnt, field) ((cnt).field += 1)
+#define WC_WAVE(cnt, field)                                                              \
+    do {                                                                                 \
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) (cnt).field += 1; \
+    } while (0)
+DEV void walk_count_flush(WalkCount &c, int base)
+{
+    unsigned long long v[7] = {c.rays, c.lane_nodes, c.wave_nodes, c.lane_prims, c.wave_prims, c.lane_leaves, c.wave_rounds};
+    for (int k = 0; k < 7; ++k) {
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&g_walk_counts[base + k], x);
+    }
+}
+#else
+#define WC_ADD(cnt, field) ((void)0)
+#define WC_WAVE(cnt, field) ((void)0)
+#endif
+
 // ------------------------------------------------------------------ hierarchy traversal
 // Stack of pending nodes in LDS: entry k of a lane lives at stack[k * 256 + lane-in-block], so a
 // wave's push or pop touches 64 consecutive banks.
@@ -373,31 +425,71 @@ DEV bool trace_shadow(const DevScene &S, d3 o, d3 d, int parent, double maxT, bo
 DEV int leaf_begin(int code) { return (-2 - code) >> 2; }
 DEV int leaf_count(int code) { return ((-2 - code) & 3) + 1; }
 
-// Single-precision view of a ray for the slab tests.  The boxes are already rounded outward; what
-// is left to cover is the rounding of the origin, of the subtractions and of the reciprocal.  The
-// first two are spatial errors of at most 2^-23 (|o| + |plane|): the origin is shifted by `pad`
-// (eight times that) towards each plane's conservative side.  The products carry a relative error
-// of a few 2^-24, covered by the factors (1 -+ 2^-19) in box4_entry.
+// Dynamic LDS of the traversal kernels: the per-thread stacks, then a copy of the first nodes of
+// the two hierarchies (breadth-first order, so the top of each tree).  Every ray reads the top
+// nodes, each lane its own 128 bytes per step; served from the vector cache those reads alone keep
+// the cache's 64-byte/clock port busy for longer than the arithmetic takes.  A cached node
+// occupies 36 words instead of 32: with a stride of 32 every node would start in the same bank.
+extern __shared__ __align__(16) int s_lds[];
+#define NODE_LDS_WORDS 36
+DEV void fill_node_cache(const DevScene &S)
+{
+    const int words = (S.tri_cached + S.sph_cached) * 32;
+    const int *tsrc = reinterpret_cast<const int *>(S.tri_nodes);
+    const int *ssrc = reinterpret_cast<const int *>(S.sph_nodes);
+    for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) {
+        const int node = i >> 5, w = i & 31;
+        const int v = node < S.tri_cached ? tsrc[i] : ssrc[i - S.tri_cached * 32];
+        s_lds[S.lds_cache_word + node * NODE_LDS_WORDS + w] = v;
+    }
+    __syncthreads();
+}
+
+// Single-precision view of a ray for the slab tests.  A child box passes when the ray's
+// parameter interval inside it, [tn, tf] clipped to [0, limit], is not empty.  Per axis
+// t = plane * (1/d) - origin * (1/d), one fused multiply-add per plane; the near plane of an axis
+// is the lower bound when the direction is positive, else the upper bound, so the node is read
+// through a per-ray byte offset and no min/max per axis is needed.
+//
+// The test must never reject a box the exact ray touches.  The boxes are already rounded outward.
+// Spatial errors (the origin converted to float, the product origin * (1/d) -- each at most
+// 2^-24 (|o| + pad) once divided by |1/d|) are covered by moving the origin by `pad`, eight times
+// that, away from each plane: lower bounds are taken against o + pad, upper bounds against
+// o - pad, which is the box grown by pad.  Relative errors (1/d: conversion and division; the
+// rounding of the fused operation) are a few 2^-24 of t and are covered by the factor 1 + 2^-17
+// on tf in the comparison.
 struct RayBox4 {
-    float olx, oly, olz;   // origin + pad, used against the `lo` planes
-    float ohx, ohy, ohz;   // origin - pad, used against the `hi` planes
-    float ix, iy, iz;      // 1 / direction
+    float ix, iy, iz;        // 1 / direction
+    float cnx, cny, cnz;     // (origin moved away from the near plane) * (1 / direction)
+    float cfx, cfy, cfz;     // (origin moved away from the far plane) * (1 / direction)
+    uint32_t sx, sy, sz;     // byte offset of the near planes of an axis in a node: 0 (lower) or 16 (upper) + 32 * axis
 };
 DEV float inv_dir(double d)
 {
     // an (almost) axis-parallel ray is nudged for the box test only: 0 * inf would be NaN
     const float df = (float)d;
-    const float dd = fabsf(df) < 1e-30f ? (d < 0 ? -1e-30f : 1e-30f) : df;
-    return 1.0f / dd;      // conversion + division: a few 2^-24 of relative error, inside the 2^-19 slack
+    const float dd = fabsf(df) < 1e-25f ? (d < 0 ? -1e-25f : 1e-25f) : df;
+    return __builtin_amdgcn_rcpf(dd);   // one ulp: inside the relative slack of the comparison
 }
 DEV RayBox4 make_raybox4(d3 o, d3 d, float bound)
 {
     RayBox4 r;
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-    const float pad = 0x1p-21f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + bound);
-    r.olx = ox + pad; r.oly = oy + pad; r.olz = oz + pad;
-    r.ohx = ox - pad; r.ohy = oy - pad; r.ohz = oz - pad;
+    const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+    const float pad = 0x1p-21f * (omax + bound);
     r.ix = inv_dir(d.x); r.iy = inv_dir(d.y); r.iz = inv_dir(d.z);
+    const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
+    r.sx = nx ? 16u : 0u; r.sy = ny ? 48u : 32u; r.sz = nz ? 80u : 64u;
+    // lower bounds pair with o + pad, upper bounds with o - pad
+    r.cnx = (nx ? ox - pad : ox + pad) * r.ix; r.cfx = (nx ? ox + pad : ox - pad) * r.ix;
+    r.cny = (ny ? oy - pad : oy + pad) * r.iy; r.cfy = (ny ? oy + pad : oy - pad) * r.iy;
+    r.cnz = (nz ? oz - pad : oz + pad) * r.iz; r.cfz = (nz ? oz + pad : oz - pad) * r.iz;
+    if (!(omax < 1e12f)) {
+        // an origin this far away would overflow the products: let every box pass instead
+        r.ix = r.iy = r.iz = 0.0f;
+        r.cnx = r.cny = r.cnz = 1.0f;
+        r.cfx = r.cfy = r.cfz = -3.0e38f;
+    }
     return r;
 }
 DEV float limit_f32(double limit)
@@ -406,17 +498,56 @@ DEV float limit_f32(double limit)
     return lf + fabsf(lf) * 0x1p-22f;   // never below the double it came from
 }
 
-// Conservative entry distance of child c of a 4-wide node, or +inf when the ray misses it within
-// [0, limit].
-DEV float box4_entry(const accel::Bvh4Node *n, int c, const RayBox4 &r, float limitf)
+// Conservative entry distances of the four children of node `cur` (+inf: missed within
+// [0, limit] or no child), and their codes.  The first `cached` nodes of this hierarchy start at LDS word `lds_word`.
+DEV void box4_test(const accel::Bvh4Node *nodes, int cached, int lds_word, int cur, const RayBox4 &r, float limitf,
+                   float k[4], int c[4])
 {
-    const float ax = (n->lo[0][c] - r.olx) * r.ix, bx = (n->hi[0][c] - r.ohx) * r.ix;
-    const float ay = (n->lo[1][c] - r.oly) * r.iy, by = (n->hi[1][c] - r.ohy) * r.iy;
-    const float az = (n->lo[2][c] - r.olz) * r.iz, bz = (n->hi[2][c] - r.ohz) * r.iz;
-    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), limitf));
-    const bool hit = n->child[c] != BVH_NONE && tn * (1.0f - 0x1p-19f) <= tf * (1.0f + 0x1p-19f);
-    return hit ? tn : __builtin_inff();
+    // The two sources are read through pointers of explicit address spaces: with generic pointers the
+    // compiler merges the branches into flat loads, which take the slow path for LDS addresses.
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const v4f lds_v4f;
+    typedef __attribute__((address_space(3))) const v4i lds_v4i;
+    typedef __attribute__((address_space(1))) const v4f glb_v4f;
+    typedef __attribute__((address_space(1))) const v4i glb_v4i;
+    v4f nx, fx, ny, fy, nz, fz;
+    v4i code;
+    if (cur < cached) {
+        __attribute__((address_space(3))) const int *lw = (__attribute__((address_space(3))) const int *)s_lds + (lds_word + cur * NODE_LDS_WORDS);
+        nx = *(lds_v4f *)(lw + (r.sx >> 2));
+        fx = *(lds_v4f *)(lw + ((r.sx ^ 16u) >> 2));
+        ny = *(lds_v4f *)(lw + (r.sy >> 2));
+        fy = *(lds_v4f *)(lw + ((r.sy ^ 16u) >> 2));
+        nz = *(lds_v4f *)(lw + (r.sz >> 2));
+        fz = *(lds_v4f *)(lw + ((r.sz ^ 16u) >> 2));
+        code = *(lds_v4i *)(lw + 24);
+    } else {
+        __attribute__((address_space(1))) const char *base = (__attribute__((address_space(1))) const char *)nodes;
+        const uint32_t nb = (uint32_t)cur * 128u;
+        nx = *(glb_v4f *)(base + (nb + r.sx));
+        fx = *(glb_v4f *)(base + (nb + (r.sx ^ 16u)));
+        ny = *(glb_v4f *)(base + (nb + r.sy));
+        fy = *(glb_v4f *)(base + (nb + (r.sy ^ 16u)));
+        nz = *(glb_v4f *)(base + (nb + r.sz));
+        fz = *(glb_v4f *)(base + (nb + (r.sz ^ 16u)));
+        code = *(glb_v4i *)(base + (nb + 96u));
+    }
+    const float inf = __builtin_inff();
+#define BOX4_CHILD(i, m)                                                                                          \
+    do {                                                                                                          \
+        const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(nx.m, r.ix, -r.cnx), __builtin_fmaf(ny.m, r.iy, -r.cny)), \
+                                     __builtin_fmaf(nz.m, r.iz, -r.cnz)), 0.0f);                                   \
+        const float tf = fminf(fminf(fminf(__builtin_fmaf(fx.m, r.ix, -r.cfx), __builtin_fmaf(fy.m, r.iy, -r.cfy)), \
+                                     __builtin_fmaf(fz.m, r.iz, -r.cfz)), limitf);                                 \
+        c[i] = code.m;                                                                                            \
+        k[i] = (code.m != BVH_NONE && tn <= tf * (1.0f + 0x1p-17f)) ? tn : inf;                                    \
+    } while (0)
+    BOX4_CHILD(0, x);
+    BOX4_CHILD(1, y);
+    BOX4_CHILD(2, z);
+    BOX4_CHILD(3, w);
+#undef BOX4_CHILD
 }
 
 #define BVH_SORT2(ka, ca, kb, cb)                          \
@@ -430,12 +561,14 @@ DEV float box4_entry(const accel::Bvh4Node *n, int c, const RayBox4 &r, float li
 
 // One step down from inner node `cur`: tests its (up to) four child boxes, continues with the
 // nearest hit child and stacks the others, farthest first (or pops when nothing is hit).
-DEV int bvh4_step(const accel::Bvh4Node *nodes, int cur, const RayBox4 &rb, float limitf, bool ordered, int *stack, int &sp)
+DEV int bvh4_step(const accel::Bvh4Node *nodes, int cached, int lds_word, int cur, const RayBox4 &rb, float limitf,
+                  bool ordered, int *stack, int &sp)
 {
-    const accel::Bvh4Node *n = &nodes[cur];
-    float k0 = box4_entry(n, 0, rb, limitf), k1 = box4_entry(n, 1, rb, limitf);
-    float k2 = box4_entry(n, 2, rb, limitf), k3 = box4_entry(n, 3, rb, limitf);
-    int c0 = n->child[0], c1 = n->child[1], c2 = n->child[2], c3 = n->child[3];
+    float kk[4];
+    int cc[4];
+    box4_test(nodes, cached, lds_word, cur, rb, limitf, kk, cc);
+    float k0 = kk[0], k1 = kk[1], k2 = kk[2], k3 = kk[3];
+    int c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3];
     const float inf = __builtin_inff();
     if (ordered) {
         BVH_SORT2(k0, c0, k1, c1);
@@ -448,11 +581,13 @@ DEV int bvh4_step(const accel::Bvh4Node *nodes, int cur, const RayBox4 &rb, floa
         if (k1 < inf) { stack[sp * 256] = c1; ++sp; }
         if (k0 < inf) return c0;
     } else {
-        // any order: hit children go to the stack, the last one pushed is taken straight back
-        if (k0 < inf) { stack[sp * 256] = c0; ++sp; }
-        if (k1 < inf) { stack[sp * 256] = c1; ++sp; }
-        if (k2 < inf) { stack[sp * 256] = c2; ++sp; }
-        if (k3 < inf) { stack[sp * 256] = c3; ++sp; }
+        // any order: the last hit child is kept in hand, the others go to the stack
+        int next = BVH_NONE;
+        if (k0 < inf) next = c0;
+        if (k1 < inf) { if (next != BVH_NONE) { stack[sp * 256] = next; ++sp; } next = c1; }
+        if (k2 < inf) { if (next != BVH_NONE) { stack[sp * 256] = next; ++sp; } next = c2; }
+        if (k3 < inf) { if (next != BVH_NONE) { stack[sp * 256] = next; ++sp; } next = c3; }
+        if (next != BVH_NONE) return next;
     }
     if (sp == 0) return BVH_NONE;
     --sp;
@@ -468,21 +603,31 @@ struct Best {
 // Nearest hit over one hierarchy.  TRI selects the leaf record type.  Two phases per round:
 // every lane descends until it holds a leaf (or is done), then the wave tests leaves together.
 template <bool TRI>
-DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, Best &best, int *stack)
+DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, Best &best, int *stack, WalkCount &wc)
 {
     const double minT = .01, maxT = 10000000000.0;
     const accel::Bvh4Node *nodes = TRI ? S.tri_nodes : S.sph_nodes;
     if ((TRI ? S.n_tri_nodes : S.n_sph_nodes) == 0) return;
+    const int cached = TRI ? S.tri_cached : S.sph_cached;
+    const int lds_word = S.lds_cache_word + (TRI ? 0 : S.tri_cached * NODE_LDS_WORDS);
     int cur = 0, sp = 0;
     while (true) {
         const float limitf = limit_f32(best.t * (1.0 + 1e-12) + 1e-12);
-        while (cur >= 0) cur = bvh4_step(nodes, cur, rb, limitf, true, stack, sp);
+        WC_WAVE(wc, wave_rounds);
+        while (cur >= 0) {
+            WC_ADD(wc, lane_nodes);
+            WC_WAVE(wc, wave_nodes);
+            cur = bvh4_step(nodes, cached, lds_word, cur, rb, limitf, true, stack, sp);
+        }
         if (cur == BVH_NONE) break;
+        WC_ADD(wc, lane_leaves);
         const int b = leaf_begin(cur), e = b + leaf_count(cur);
         for (int k = b; k < e; ++k) {
             double t;
             int key;
-            if (TRI) { t = tri_test_fast(&S.btri[k], o, d, minT, maxT, best.t); key = S.btri[k]._pad0; }
+            WC_ADD(wc, lane_prims);
+            WC_WAVE(wc, wave_prims);
+            if (TRI) { const TriOps tr = load_tri(&S.btri[k]); t = tri_test_fast(tr, o, d, minT, maxT, best.t); key = tr.key; }
             else { t = sph_test(&S.bsph[k], o, d, d2, minT, maxT); key = S.bsph_key[k]; }
             if (t < best.t || (t == best.t && t < maxT && key < best.key)) {
                 best.t = t; best.key = key; best.slot = TRI ? k : (k | SLOT_SPHERE);
@@ -496,22 +641,34 @@ DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb
 
 // Any hit in (minT, maxT) by a primitive other than `parent`.
 template <bool TRI>
-DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, int parent, double maxT, int *stack)
+DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, int parent, double maxT, int *stack,
+                 WalkCount &wc)
 {
     const double minT = .01;
     const accel::Bvh4Node *nodes = TRI ? S.tri_nodes : S.sph_nodes;
     if ((TRI ? S.n_tri_nodes : S.n_sph_nodes) == 0) return false;
+    const int cached = TRI ? S.tri_cached : S.sph_cached;
+    const int lds_word = S.lds_cache_word + (TRI ? 0 : S.tri_cached * NODE_LDS_WORDS);
     const float limitf = limit_f32(maxT * (1.0 + 1e-12) + 1e-12);
     int cur = 0, sp = 0;
     while (true) {
-        while (cur >= 0) cur = bvh4_step(nodes, cur, rb, limitf, false, stack, sp);
+        WC_WAVE(wc, wave_rounds);
+        while (cur >= 0) {
+            WC_ADD(wc, lane_nodes);
+            WC_WAVE(wc, wave_nodes);
+            cur = bvh4_step(nodes, cached, lds_word, cur, rb, limitf, false, stack, sp);
+        }
         if (cur == BVH_NONE) break;
+        WC_ADD(wc, lane_leaves);
         const int b = leaf_begin(cur), e = b + leaf_count(cur);
         for (int k = b; k < e; ++k) {
             double t;
+            WC_ADD(wc, lane_prims);
+            WC_WAVE(wc, wave_prims);
             if (TRI) {
-                if (S.btri[k].prim == parent) continue;
-                t = tri_test_fast(&S.btri[k], o, d, minT, maxT, maxT);
+                const TriOps tr = load_tri(&S.btri[k]);
+                if (tr.prim == parent) continue;
+                t = tri_test_fast(tr, o, d, minT, maxT, maxT);
             } else {
                 if ((int)(S.bsph_prim[k] & ~RT_SPH_TRANSPARENT) == parent) continue;
                 t = sph_test(&S.bsph[k], o, d, d2, minT, maxT);
@@ -749,8 +906,8 @@ template <bool PRIMARY, bool BVH>
 __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, QueueSet Q)
 {
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
-    extern __shared__ int s_stack[];
-    int *stack = &s_stack[BVH ? threadIdx.x : 0];
+    int *stack = &s_lds[BVH ? threadIdx.x : 0];
+    if (BVH) fill_node_cache(P.S);
     const int lane = (int)(threadIdx.x & 63);
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
@@ -759,6 +916,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
     if (!PRIMARY) smap = shard_map(&Q.counts[CNT_RAYS(Q.generation)], Q.in_shard_cap, 1u);
     const long long n_chunks = PRIMARY ? (Q.chunk_end - Q.chunk_begin) : (long long)smap.total;
     const bool cull = P.cull_closest != 0;
+    WalkCount wc{};
 
     for (long long chunk = wave; chunk < n_chunks; chunk += n_waves) {
         bool active;
@@ -842,8 +1000,9 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
                 bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1;
                 if (root_gate(P.S, o, d, d2, 10000000000.0)) {
                     const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
-                    bvh_closest<true>(P.S, o, d, d2, rb, bst, stack);
-                    bvh_closest<false>(P.S, o, d, d2, rb, bst, stack);
+                    WC_ADD(wc, rays);
+                    bvh_closest<true>(P.S, o, d, d2, rb, bst, stack, wc);
+                    bvh_closest<false>(P.S, o, d, d2, rb, bst, stack, wc);
                 }
                 best_t = bst.t;
                 best = bst.slot;
@@ -926,6 +1085,9 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
             }
         }
     }
+#ifdef RT_COUNT
+    walk_count_flush(wc, PRIMARY ? 0 : 8);
+#endif
 }
 
 // The same query for a whole wave at once (every lane calls it; `active` lanes hold a query).
@@ -1034,14 +1196,15 @@ template <bool BVH>
 __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams P, QueueSet Q)
 {
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
-    extern __shared__ int s_stack[];
-    int *stack = &s_stack[BVH ? threadIdx.x : 0];
+    int *stack = &s_lds[BVH ? threadIdx.x : 0];
+    if (BVH) fill_node_cache(P.S);
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     const uint32_t nl = (uint32_t)P.S.n_lights;
     // work items are (hit, light) pairs, the lights of one hit in consecutive items
     const ShardMap smap = shard_map(&Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, nl);
     const bool cull = P.cull_shadow != 0;
+    WalkCount wc{};
     for (long long chunk = wave; chunk < (long long)smap.total; chunk += n_waves) {
         int shard;
         const int item = shard_locate(smap, (uint32_t)chunk, &shard);
@@ -1069,8 +1232,9 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
                 occluded = false;
                 if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
                     const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
-                    occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack) ||
-                               bvh_any<false>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack);
+                    WC_ADD(wc, rays);
+                    occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack, wc) ||
+                               bvh_any<false>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack, wc);
                 }
             } else {
                 occluded = trace_shadow(P.S, Pt, rd, hr->prim, maxT, cull, &only, &closest);
@@ -1103,6 +1267,9 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
         }
         accum_add_runs(P.accum, active, lit, pixel, hr->weight, local);
     }
+#ifdef RT_COUNT
+    walk_count_flush(wc, 16);
+#endif
 }
 
 // Deferred light-camera evaluations of one generation: density query, then the same shading as a
@@ -1284,6 +1451,7 @@ struct rt_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_shadow;
     size_t ev_closest_used = 0, ev_shadow_used = 0;
     int cu_count = 256;
+    size_t lds_per_cu = 64 * 1024;   // LDS of one compute unit (maxSharedMemoryPerMultiProcessor)
 };
 
 static void free_lightcams(rt_ctx *ctx)
@@ -1340,6 +1508,7 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
     rt_ctx *ctx = new rt_ctx();
     ctx->device = device_id;
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) ctx->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     for (int k = 0; k < 6; ++k) {
@@ -1359,7 +1528,7 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shadow<true>, 256, lds);
             fprintf(stderr, "[rt] k_shadow<bvh> lds=%zu: %d blocks/CU\n", lds, n);
         }
-        fprintf(stderr, "[rt] CUs=%d\n", ctx->cu_count);
+        fprintf(stderr, "[rt] CUs=%d LDS/CU=%zu sharedMemPerBlock=%zu\n", ctx->cu_count, ctx->lds_per_cu, (size_t)prop.sharedMemPerBlock);
     }
     *out = ctx;
     return RT_OK;
@@ -1391,6 +1560,18 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     delete ctx;
     return RT_OK;
 }
+
+#ifdef RT_COUNT
+// Diagnostic builds: totals since the last call, 3 groups (primary, queued closest, shadow) x 8 words.
+extern "C" int rt_debug_counters(unsigned long long *out24)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_walk_counts), 24 * sizeof(unsigned long long)));
+    unsigned long long zero[32] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_counts), zero, sizeof zero));
+    return RT_OK;
+}
+#endif
 
 extern "C" int rt_set_batch(rt_ctx *ctx, int64_t primaries)
 {
@@ -1702,8 +1883,28 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     int stack_entries = 3 * ctx->accel_depth + 1;
     if (stack_entries > BVH_STACK) stack_entries = BVH_STACK;
     if (stack_entries < 4) stack_entries = 4;
-    const size_t lds_closest = bvh_closest_ok ? (size_t)stack_entries * 256 * sizeof(int) : 0;
-    const size_t lds_shadow = bvh_shadow_ok ? (size_t)stack_entries * 256 * sizeof(int) : 0;
+    // LDS per block: the stacks, then as many top-of-tree nodes as fit beside them when four blocks
+    // share a compute unit (the register budget allows four waves per SIMD)
+    const size_t lds_stack = (size_t)stack_entries * 256 * sizeof(int);
+    {
+        const size_t per_block = ctx->lds_per_cu / 4;
+        long long room = per_block > lds_stack + 512 ? (long long)((per_block - lds_stack - 512) / (NODE_LDS_WORDS * 4)) : 0;
+        if (const char *e = std::getenv("RT_NODE_CACHE")) room = std::atoll(e) < room ? std::atoll(e) : room;   // experiments
+        // the triangle hierarchy first, the sphere hierarchy takes what is left; split evenly when both are large
+        long long nt = P.S.n_tri_nodes, ns = P.S.n_sph_nodes;
+        if (nt + ns > room) {
+            const long long half = room / 2;
+            if (nt <= half) ns = room - nt;
+            else if (ns <= half) nt = room - ns;
+            else { nt = half; ns = room - half; }
+        }
+        P.S.tri_cached = (int32_t)nt;
+        P.S.sph_cached = (int32_t)ns;
+        P.S.lds_cache_word = (int32_t)(lds_stack / sizeof(int));
+    }
+    const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int);
+    const size_t lds_closest = bvh_closest_ok ? lds_bvh : 0;
+    const size_t lds_shadow = bvh_shadow_ok ? lds_bvh : 0;
 
     hipStream_t st = ctx->stream;
     HIP_TRY(hipEventRecord(ctx->ev_begin, st));

@@ -1,0 +1,25 @@
+"""Prints traversal statistics of one frame from a -DRT_COUNT build of the library.
+usage: RAYTRACER_AMD_LIB=build_variants/lib_count.so python tools/walk_stats.py [workload]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracer_amd as rt
+import bench
+w = sys.argv[1] if len(sys.argv) > 1 else "teapot3"
+scene_name, resx, resy, N, _, _ = bench.WORKLOADS[w]
+lib = rt.load()
+fn = C.CDLL(rt.LIB_PATH).rt_debug_counters
+fn.argtypes = [C.POINTER(C.c_ulonglong)]
+s = rt.Scene.load(scene_name); g = rt.Renderer(0); g.upload(s)
+cam = s.camera(resx, resy)
+buf = (C.c_ulonglong * 24)()
+fn(buf)
+fr = g.render(cam, num_samples=N, want=("rgb_u8",))
+fn(buf)
+names = ["rays", "lane_nodes", "wave_nodes", "lane_prims", "wave_prims", "lane_leaves", "wave_rounds"]
+print(w, fr["stats"]["closest_rays"], fr["stats"]["shadow_rays"])
+for gi, gname in enumerate(("primary", "queued", "shadow")):
+    v = dict(zip(names, list(buf[gi * 8:gi * 8 + 7])))
+    r = max(v["rays"], 1)
+    print("%-8s rays %11d | per ray: nodes %.2f leaves %.2f prims %.2f | per 64 rays the wave ran: node steps %.1f prim tests %.1f rounds %.1f"
+          % (gname, v["rays"], v["lane_nodes"] / r, v["lane_leaves"] / r, v["lane_prims"] / r,
+             v["wave_nodes"] * 64 / r, v["wave_prims"] * 64 / r, v["wave_rounds"] * 64 / r))
