@@ -1976,9 +1976,14 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             return fail(RT_ERR_INVALID, "rt_render: batch too large for 32-bit queue indices");
         if ((rc = ensure(&ctx->rays[0], &ctx->ray_capacity[0], (size_t)(need_rays[0] ? need_rays[0] : 64))) != RT_OK) return rc;
         if ((rc = ensure(&ctx->rays[1], &ctx->ray_capacity[1], (size_t)(need_rays[1] ? need_rays[1] : 64))) != RT_OK) return rc;
-        // four hit buffers: [batch parity][generation parity], so that the shadow pass of one
-        // generation (second stream) can run beside the closest-hit pass of the next one
-        for (int k = 0; k < 4; ++k)
+        // Overlap pays when a pass cannot fill the chip by itself (small frames: each pass is one
+        // ray's latency long); big batches already saturate it with one persistent grid, and there
+        // the extra ordering constraints only cost, so they run on one stream.
+        const bool overlap = batch_chunks * 64 <= (1ll << 22);
+        // with overlap, four hit buffers: [batch parity][generation parity], so that the shadow pass of
+        // one generation (second stream) can run beside the closest-hit pass of the next one; on one
+        // stream a single buffer serves every pass
+        for (int k = 0; k < (overlap ? 4 : 1); ++k)
             if ((rc = ensure(&ctx->hits[k], &ctx->hit_capacity[k], (size_t)need_hits)) != RT_OK) return rc;
         const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
         if (use_lightcam && (rc = ensure(&ctx->deferred, &ctx->deferred_capacity, (size_t)need_hits)) != RT_OK) return rc;
@@ -1988,10 +1993,6 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         // waits for S_g (it re-uses S_g's hit buffer); a batch's memset waits for the roll-up of
         // the batch two before it (same counter block).  Pixel accumulation is atomic, so the
         // order in which the passes finish does not matter.
-        // Overlap pays when a pass cannot fill the chip by itself (small frames: each pass is one
-        // ray's latency long); big batches already saturate it with one persistent grid, and there
-        // the extra ordering constraints only cost, so they run on one stream.
-        const bool overlap = batch_chunks * 64 <= (1ll << 22);
         hipStream_t sb = overlap ? ctx->stream2 : st;
         const bool timing = (o->flags & RT_FLAG_TIMING) != 0;
         long long batch_no = 0;
@@ -2005,7 +2006,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 QueueSet Q{};
                 Q.rays_in = ctx->rays[g & 1];
                 Q.rays_out = ctx->rays[(g + 1) & 1];
-                Q.hits = ctx->hits[par * 2 + (g & 1)];
+                Q.hits = ctx->hits[overlap ? par * 2 + (g & 1) : 0];
                 Q.deferred = ctx->deferred;
                 Q.counts = counts;
                 Q.in_shard_cap = (uint32_t)ray_cap[g];
