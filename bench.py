@@ -15,6 +15,8 @@ Workloads (BASELINE.json `configs`):
     balls         balls.nff 512x512, 1 spp
     refract       refract.nff 512x512, 1 spp
     glass         glass.nff 900x900, 1 spp (light-camera caustics on; the reference's hide.ppm frame)
+    gears         gears.nff 512x512, 1 spp (36 k triangles, transparent materials, 5 lights)
+    balls2        balls2.nff 512x512, 1 spp (every ray reflects to the depth limit)
 
 For N > 1 launch as: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
 --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -35,6 +37,8 @@ WORKLOADS = {
     "balls": ("balls", 0, 0, 1, 50, 5),
     "refract": ("refract", 0, 0, 1, 50, 5),
     "glass": ("glass", 0, 0, 1, 20, 3),
+    "gears": ("gears", 0, 0, 1, 20, 3),
+    "balls2": ("balls2", 0, 0, 1, 20, 3),
 }
 HBM_PEAK_GBPS = 8000.0
 BAND_ROWS = 16

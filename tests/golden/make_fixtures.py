@@ -22,7 +22,7 @@ REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 SCENES = ["tetra-3", "teapot-3", "balls", "refract", "glass", "glass2", "glass3", "glass4",
-          "ball", "ball2", "2d", "teapot-1", "teapot-2", "tetra-5"]
+          "ball", "ball2", "2d", "teapot-1", "teapot-2", "tetra-5", "teapot", "tetra", "gears", "balls2"]
 
 # Outputs of the reference binary itself (g++ -O3 build of the unmodified sources, 1 spp,
 # aperture 0), recorded when the reference was surveyed: first 12 hex digits of the sha256 of

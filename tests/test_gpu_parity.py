@@ -62,6 +62,21 @@ def test_scene_matches_oracle(gpu, oracle_frame, scene):
     assert g["stats"]["queue_overflow"] == 0
 
 
+# The reference's larger scenes at a reduced resolution (the oracle renders them in seconds):
+# gears has 36 k triangles, 65 materials with T = 0.8 and 5 lights (refraction fan-out, a hierarchy
+# that does not fit the on-chip node cache); balls2 reflects every ray to the depth limit.
+@pytest.mark.parametrize("scene,res", [("teapot", (256, 256)), ("tetra", (300, 300)), ("gears", (160, 160)),
+                                       ("balls2", (200, 200))])
+def test_large_scenes(gpu, oracle_frame, scene, res):
+    s = load_scene(gpu, scene)
+    g = gpu.render(s.camera(*res), flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    o = oracle_frame(scene, res=res)
+    assert_frames_match(g, o)
+    assert g["stats"]["closest_rays"] == o["counters"]["closest_rays"]
+    assert g["stats"]["shadow_rays"] == o["counters"]["shadow_rays"]
+    assert g["stats"]["queue_overflow"] == 0
+
+
 @pytest.mark.parametrize("scene", ["teapot-3", "balls"])
 def test_pruned_walk_equals_reference_walk(gpu, scene):
     """Pruning by entry distance and dropping zero-weight rays change no output value."""

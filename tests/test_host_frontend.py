@@ -15,7 +15,7 @@ import raytracer_amd as rt
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALL_SCENES = ["tetra-3", "teapot-3", "balls", "refract", "glass", "glass2", "glass3", "glass4", "ball", "ball2", "2d",
-              "teapot-1", "teapot-2", "tetra-5"]
+              "teapot-1", "teapot-2", "tetra-5", "teapot", "tetra", "gears", "balls2"]
 
 
 def test_library_exports_every_declared_symbol():
