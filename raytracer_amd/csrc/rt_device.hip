@@ -888,8 +888,10 @@ DEV void accum_add_runs(double *accum, bool in_queue, bool valid, uint32_t pixel
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int orun = __shfl_down(run, off);
+        const bool same = lane + off < 64 && orun == run;
+        if (__ballot(same) == 0) break;      // runs are contiguous: no partner at this distance, none farther
         const double ox = __shfl_down(vx, off), oy = __shfl_down(vy, off), oz = __shfl_down(vz, off);
-        if (lane + off < 64 && orun == run) { vx += ox; vy += oy; vz += oz; }
+        if (same) { vx += ox; vy += oy; vz += oz; }
     }
     if (in_queue && head && (vx != 0.0 || vy != 0.0 || vz != 0.0)) {
         unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 0], vx);
@@ -1032,57 +1034,63 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
         }
         if (PRIMARY && active && first_sample && P.hit_id) P.hit_id[pixel] = prim;
 
-        // hit queue for the shadow/shading pass
-        {
-            bool ok;
-            bool want = hit && P.S.n_lights > 0;
-            uint32_t slot = wave_reserve(want, &Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, &Q.counts[CNT_OVERFLOW], &ok);
-            if (ok) {
-                HitRec *h = &Q.hits[slot];
-                h->P[0] = Pt.x; h->P[1] = Pt.y; h->P[2] = Pt.z;
-                const d3 n2 = unit3(n);
-                const d3 vv = unit3(sub3(o, Pt));
-                const d3 n3 = unit3(n2);
-                h->n[0] = n2.x; h->n[1] = n2.y; h->n[2] = n2.z;
-                h->nn[0] = n3.x; h->nn[1] = n3.y; h->nn[2] = n3.z;
-                h->v[0] = vv.x; h->v[1] = vv.y; h->v[2] = vv.z;
-                h->weight = wloc;
-                h->pixel = pixel;
-                h->prim = prim;
-            }
+        // Queue pushes.  The three reservations (hit record, refraction ray, reflection ray) are made
+        // with two atomics -- both kinds of ray go to the same queue -- issued back to back by one lane,
+        // so a wave waits for one round trip to the counters instead of three in a row.
+        const bool want_hit = hit && P.S.n_lights > 0;
+        const bool spawn = hit && L > 0 && !(coef < .01);       // Camera.h:244-307
+        const double coef2 = coef * m.Ks;
+        const bool want_refr = spawn && m.T > 0;
+        const bool want_refl = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
+        const unsigned long long mask_h = __ballot(want_hit), mask_a = __ballot(want_refr), mask_b = __ballot(want_refl);
+        const uint32_t n_h = (uint32_t)__popcll(mask_h), n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b);
+        const uint32_t shard = blockIdx.x & (N_SHARDS - 1);
+        uint32_t base_h = 0, base_r = 0;
+        if (lane == 0) {
+            if (n_h) base_h = atomicAdd(&Q.counts[CNT_HITS(Q.generation) + shard], n_h);
+            if (n_a + n_b) base_r = atomicAdd(&Q.counts[CNT_RAYS(Q.generation + 1) + shard], n_a + n_b);
         }
+        base_h = (uint32_t)__shfl((int)base_h, 0);
+        base_r = (uint32_t)__shfl((int)base_r, 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t slot_h = base_h + (uint32_t)__popcll(mask_h & below);
+        const uint32_t slot_a = base_r + (uint32_t)__popcll(mask_a & below);
+        const uint32_t slot_b = base_r + n_a + (uint32_t)__popcll(mask_b & below);
+        if ((want_hit && slot_h >= Q.hit_shard_cap) || (want_refr && slot_a >= Q.out_shard_cap) ||
+            (want_refl && slot_b >= Q.out_shard_cap))
+            Q.counts[CNT_OVERFLOW] = 1u;
 
-        // secondary rays (Camera.h:244-307)
-        const bool spawn = hit && L > 0 && !(coef < .01);
-        {
-            bool want = spawn && m.T > 0;
-            bool ok;
-            uint32_t slot = wave_reserve(want, &Q.counts[CNT_RAYS(Q.generation + 1)], Q.out_shard_cap, &Q.counts[CNT_OVERFLOW], &ok);
-            if (ok) {
-                const d3 rd = refract_dir(d, n, m.ior, false);
-                RayRec *r = &Q.rays_out[slot];
-                r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
-                r->d[0] = rd.x; r->d[1] = rd.y; r->d[2] = rd.z;
-                r->A = A * m.T;
-                r->coef = m.T * coef;
-                r->pixel = pixel;
-                r->meta = (uint32_t)(L - 1) | 0x100u;
-            }
+        if (want_hit && slot_h < Q.hit_shard_cap) {
+            HitRec *h = &Q.hits[(size_t)shard * Q.hit_shard_cap + slot_h];
+            h->P[0] = Pt.x; h->P[1] = Pt.y; h->P[2] = Pt.z;
+            const d3 n2 = unit3(n);
+            const d3 vv = unit3(sub3(o, Pt));
+            const d3 n3 = unit3(n2);
+            h->n[0] = n2.x; h->n[1] = n2.y; h->n[2] = n2.z;
+            h->nn[0] = n3.x; h->nn[1] = n3.y; h->nn[2] = n3.z;
+            h->v[0] = vv.x; h->v[1] = vv.y; h->v[2] = vv.z;
+            h->weight = wloc;
+            h->pixel = pixel;
+            h->prim = prim;
         }
-        {
-            const double coef2 = coef * m.Ks;
-            bool want = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
-            bool ok;
-            uint32_t slot = wave_reserve(want, &Q.counts[CNT_RAYS(Q.generation + 1)], Q.out_shard_cap, &Q.counts[CNT_OVERFLOW], &ok);
-            if (ok) {
-                RayRec *r = &Q.rays_out[slot];
-                r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
-                r->d[0] = refl.x; r->d[1] = refl.y; r->d[2] = refl.z;
-                r->A = A;
-                r->coef = coef2;
-                r->pixel = pixel;
-                r->meta = (uint32_t)(L - 1);
-            }
+        if (want_refr && slot_a < Q.out_shard_cap) {
+            const d3 rd = refract_dir(d, n, m.ior, false);
+            RayRec *r = &Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_a];
+            r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
+            r->d[0] = rd.x; r->d[1] = rd.y; r->d[2] = rd.z;
+            r->A = A * m.T;
+            r->coef = m.T * coef;
+            r->pixel = pixel;
+            r->meta = (uint32_t)(L - 1) | 0x100u;
+        }
+        if (want_refl && slot_b < Q.out_shard_cap) {
+            RayRec *r = &Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_b];
+            r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
+            r->d[0] = refl.x; r->d[1] = refl.y; r->d[2] = refl.z;
+            r->A = A;
+            r->coef = coef2;
+            r->pixel = pixel;
+            r->meta = (uint32_t)(L - 1);
         }
     }
 #ifdef RT_COUNT
@@ -1230,7 +1238,11 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
                 // no transparent sphere in the scene: "occluded" is "any hit", and never "only transparent"
                 const double d2 = dot3(rd, rd);
                 occluded = false;
+#ifdef RT_EXP_SHADOW_SKIP          /* experiment: cost of the kernel without the traversal */
+                if (false) {
+#else
                 if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
+#endif
                     const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
                     WC_ADD(wc, rays);
                     occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack, wc) ||
