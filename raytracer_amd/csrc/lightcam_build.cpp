@@ -35,6 +35,7 @@ int32_t build_node(Work &w, double lox, double loy, double loz, double size, int
     nd.begin = begin;
     nd.end = end;
     nd.leaf = 1;
+    nd.rest_begin = begin;
     for (int k = 0; k < 8; ++k) nd.child[k] = -1;
     const int32_t n = end - begin;
     if (size / 2 > .00000001 && n > 10) {
@@ -66,6 +67,7 @@ int32_t build_node(Work &w, double lox, double loy, double loz, double size, int
         std::memcpy(pos, off, sizeof pos);
         for (int32_t i = begin; i < end; ++i) w.scratch[pos[w.which[i]]++] = w.perm[i];   // stable
         for (int32_t i = begin; i < end; ++i) w.perm[i] = w.scratch[i];
+        nd.rest_begin = off[8];
         for (int k = 0; k < 8; ++k)
             if (cnt[k] > 0)
                 nd.child[k] = build_node(w, clo[k][0], clo[k][1], clo[k][2], chi[k][0] - clo[k][0], off[k], off[k] + cnt[k]);
@@ -91,6 +93,11 @@ void build(const std::vector<Point> &pts, double max_dist_from_zero, Tree &out)
     build_node(w, 0 - size / 2, 0 - size / 2, 0 - size / 2, size, 0, static_cast<int32_t>(pts.size()));
     out.points.resize(pts.size());
     for (size_t i = 0; i < pts.size(); ++i) out.points[i] = pts[w.perm[i]];
+    for (Node &nd : out.nodes) {
+        double sum = 0;
+        for (int32_t i = nd.begin; i < nd.end; ++i) sum += out.points[i].w;
+        nd.wsum = sum;
+    }
 }
 
 namespace {

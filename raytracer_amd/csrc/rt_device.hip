@@ -748,29 +748,75 @@ DEV d3 refract_dir(d3 d, d3 n, double ior, bool renormalize)
 }
 
 // LightCam::calcIntensity + getIntensity (LightCam.h:121-203, 571-620): density of light-ray
-// impacts around `pos`, by the reference's descent rule over the point octree.
-DEV double lc_calc_intensity(const DevLightCam &cam, d3 pos)
+// impacts around `pos`.  The reference descends the point octree while a node is at least
+// 2*maxDist wide and near enough, and at the first smaller node (or a `leaf`) adds up the
+// weights of ALL of that node's points that lie within maxDist.  Which nodes are reached is
+// reproduced exactly.  Inside such a node the sum is taken hierarchically: a sub-cell wholly
+// inside the query sphere contributes its precomputed weight sum, one wholly outside nothing,
+// and only cells the sphere's surface cuts are opened down to their points, each point decided by
+// the reference's own comparison.  The caustic foci put thousands of impacts into single cells;
+// this visits a few hundred cells and points instead.  (The order of the additions differs from
+// the reference's, as it already must for any parallel sum: a rounding-level difference.)
+// COOP: every lane of the wave calls it together (`active` lanes hold a query); point ranges
+// longer than 24 are then scanned by all 64 lanes.  Without COOP a lane works alone.
+#define LC_TERMINAL 0x40000000
+template <bool COOP>
+DEV double lc_query(const DevLightCam *table, int cam_index, d3 pos, bool active)
 {
-    const d3 lp = ld3(cam.light_pos), sp = ld3(cam.sphere_pos);
-    const double smoothingFactor = 1.5;
+    const int lane = (int)(threadIdx.x & 63);
+    const DevLightCam cam = table[active ? cam_index : 0];
+    const d3 lp = ld3(cam.light_pos), spos = ld3(cam.sphere_pos);
     const double dist = norm3(sub3(pos, lp));
-    const double sphereDistToLight = norm3(sub3(lp, sp));
+    const double sphereDistToLight = norm3(sub3(lp, spos));
     double maxDist = cam.spw * (dist / sphereDistToLight);
-    maxDist *= smoothingFactor;
-    double total = 0;
+    maxDist *= 1.5;                                  // smoothingFactor
     // sqrt is monotonic and correctly rounded: |v| < maxDist is decided on the squared length
     // unless it lies within a few ulps of maxDist^2, where the reference's own comparison runs
     const double m2 = maxDist * maxDist, m2_lo = m2 * (1.0 - 0x1p-48), m2_hi = m2 * (1.0 + 0x1p-48);
-    if (cam.n_nodes > 0) {
-        // depth-first, children 0..7.  Descent stops at nodes smaller than 2*maxDist, so at most
-        // ~7 pending siblings per level over a dozen levels are ever stacked.
-        int stack[192];
-        int sp_ = 0;
-        stack[sp_++] = 0;
-        while (sp_ > 0) {
-            const lightcam::Node *r = &cam.nodes[stack[--sp_]];
-            if (r->size < maxDist * 2 || r->leaf) {
-                for (int k = r->begin; k < r->end; ++k) {
+    const double m2_in = m2 * (1.0 - 1e-9), m2_out = m2 * (1.0 + 1e-9);   // cell classification, with a margin
+    double total = 0;
+    // depth-first, children 0..7; at most 7 pending siblings per level
+    int stack[192];
+    int sp_ = 0;
+    if (active && cam.n_nodes > 0) stack[sp_++] = 0;
+    int pend_b = 0, pend_e = 0;
+    while (true) {
+        bool pending = false;
+        while (sp_ > 0 && !pending) {
+            const int code = stack[--sp_];
+            const lightcam::Node *r = &cam.nodes[code & ~LC_TERMINAL];
+            bool terminal = (code & LC_TERMINAL) != 0;
+            if (!terminal) {
+                if (r->size < maxDist * 2 || r->leaf) terminal = true;
+                else {
+                    const double epsilon = maxDist * 0.1;
+                    if (norm3(sub3(pos, mk3(r->cx, r->cy, r->cz))) < (r->size + epsilon)) {
+                        for (int c = 7; c >= 0; --c)
+                            if (r->child[c] >= 0 && sp_ < 192) stack[sp_++] = r->child[c];
+                    }
+                    continue;
+                }
+            }
+            // every point of this cell that lies within maxDist counts
+            int sb = r->begin, se = r->end;
+            if (se - sb > 8) {
+                const double h = r->size * 0.5;
+                const double ax = fabs(pos.x - r->cx), ay = fabs(pos.y - r->cy), az = fabs(pos.z - r->cz);
+                const double nx = fmax(ax - h, 0.0), ny = fmax(ay - h, 0.0), nz = fmax(az - h, 0.0);
+                const double fx = ax + h, fy = ay + h, fz = az + h;
+                const double dmin2 = (nx * nx + ny * ny) + nz * nz, dmax2 = (fx * fx + fy * fy) + fz * fz;
+                if (dmin2 > m2_out) continue;
+                if (dmax2 < m2_in) { total += r->wsum; continue; }
+                if (r->rest_begin > sb && sp_ + 8 <= 192) {   // has children: open it, its own leftover points are scanned
+                    for (int c = 7; c >= 0; --c)
+                        if (r->child[c] >= 0) stack[sp_++] = r->child[c] | LC_TERMINAL;
+                    sb = r->rest_begin;
+                }
+            }
+            if (COOP && se - sb > 24) {
+                pend_b = sb; pend_e = se; pending = true;
+            } else {
+                for (int k = sb; k < se; ++k) {
                     const lightcam::Point *q = &cam.points[k];
                     const d3 dv = sub3(mk3(q->x, q->y, q->z), pos);
                     const double s2 = dot3(dv, dv);
@@ -778,18 +824,42 @@ DEV double lc_calc_intensity(const DevLightCam &cam, d3 pos)
                     if (!inside && !(s2 > m2_hi)) inside = sqrt(s2) < maxDist;
                     if (inside) total += q->w;
                 }
-            } else {
-                const double epsilon = maxDist * 0.1;
-                if (norm3(sub3(pos, mk3(r->cx, r->cy, r->cz))) < (r->size + epsilon)) {
-                    for (int c = 7; c >= 0; --c)
-                        if (r->child[c] >= 0 && sp_ < 192) stack[sp_++] = r->child[c];
-                }
             }
+        }
+        if (!COOP) break;
+        unsigned long long mask = __ballot(pending);
+        if (mask == 0) break;     // every lane has emptied its stack
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int b = __shfl(pend_b, l), e = __shfl(pend_e, l);
+            const int ci = __shfl(cam_index, l);
+            const lightcam::Point *pts = table[ci].points;
+            const d3 qp = mk3(__shfl(pos.x, l), __shfl(pos.y, l), __shfl(pos.z, l));
+            const double qmax = __shfl(maxDist, l), qlo = __shfl(m2_lo, l), qhi = __shfl(m2_hi, l);
+            double part = 0;
+            for (int k = b + lane; k < e; k += 64) {
+                const lightcam::Point *q = &pts[k];
+                const d3 dv = sub3(mk3(q->x, q->y, q->z), qp);
+                const double s2 = dot3(dv, dv);
+                bool inside = s2 < qlo;
+                if (!inside && !(s2 > qhi)) inside = sqrt(s2) < qmax;
+                if (inside) part += q->w;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == l) total += part;
         }
     }
     const double expected = (maxDist * maxDist) / (cam.spw * cam.spw);
     return total / expected;
 }
+DEV double lc_calc_intensity(const DevLightCam *table, int cam_index, d3 pos) { return lc_query<false>(table, cam_index, pos, true); }
+DEV double lc_calc_intensity_wave(const DevLightCam *table, int cam_index, d3 pos, bool active)
+{
+    return lc_query<true>(table, cam_index, pos, active);
+}
+
 
 // Counter-based stand-in for the reference's shared rand() % 1000 / 1000 (Camera.h:99-103).
 DEV uint32_t hash_rng(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
@@ -1098,77 +1168,6 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
 #endif
 }
 
-// The same query for a whole wave at once (every lane calls it; `active` lanes hold a query).
-// Each lane walks its own octree path, but a terminal node with many points is postponed and then
-// scanned by all 64 lanes together: the caustic foci put thousands of impacts into single cells,
-// and one lane scanning them alone would hold up its whole wave.
-DEV double lc_calc_intensity_wave(const DevLightCam *table, int cam_index, d3 pos, bool active)
-{
-    const int lane = (int)(threadIdx.x & 63);
-    const DevLightCam cam = table[active ? cam_index : 0];
-    const d3 lp = ld3(cam.light_pos), spos = ld3(cam.sphere_pos);
-    const double dist = norm3(sub3(pos, lp));
-    const double sphereDistToLight = norm3(sub3(lp, spos));
-    double maxDist = cam.spw * (dist / sphereDistToLight);
-    maxDist *= 1.5;
-    const double m2 = maxDist * maxDist, m2_lo = m2 * (1.0 - 0x1p-48), m2_hi = m2 * (1.0 + 0x1p-48);
-    double total = 0;
-    int stack[192];
-    int sp_ = 0;
-    if (active && cam.n_nodes > 0) stack[sp_++] = 0;
-    int pend_b = 0, pend_e = 0;
-    while (true) {
-        bool pending = false;
-        while (sp_ > 0 && !pending) {
-            const lightcam::Node *r = &cam.nodes[stack[--sp_]];
-            if (r->size < maxDist * 2 || r->leaf) {
-                if (r->end - r->begin > 24) {
-                    pend_b = r->begin; pend_e = r->end; pending = true;
-                } else {
-                    for (int k = r->begin; k < r->end; ++k) {
-                        const lightcam::Point *q = &cam.points[k];
-                        const d3 dv = sub3(mk3(q->x, q->y, q->z), pos);
-                        const double s2 = dot3(dv, dv);
-                        bool inside = s2 < m2_lo;
-                        if (!inside && !(s2 > m2_hi)) inside = sqrt(s2) < maxDist;
-                        if (inside) total += q->w;
-                    }
-                }
-            } else {
-                const double epsilon = maxDist * 0.1;
-                if (norm3(sub3(pos, mk3(r->cx, r->cy, r->cz))) < (r->size + epsilon)) {
-                    for (int c = 7; c >= 0; --c)
-                        if (r->child[c] >= 0 && sp_ < 192) stack[sp_++] = r->child[c];
-                }
-            }
-        }
-        unsigned long long mask = __ballot(pending);
-        if (mask == 0) break;     // every lane has emptied its stack
-        while (mask) {
-            const int l = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int b = __shfl(pend_b, l), e = __shfl(pend_e, l);
-            const int ci = __shfl(cam_index, l);
-            const lightcam::Point *pts = table[ci].points;
-            const d3 qp = mk3(__shfl(pos.x, l), __shfl(pos.y, l), __shfl(pos.z, l));
-            const double qmax = __shfl(maxDist, l), qlo = __shfl(m2_lo, l), qhi = __shfl(m2_hi, l);
-            double part = 0;
-            for (int k = b + lane; k < e; k += 64) {
-                const lightcam::Point *q = &pts[k];
-                const d3 dv = sub3(mk3(q->x, q->y, q->z), qp);
-                const double s2 = dot3(dv, dv);
-                bool inside = s2 < qlo;
-                if (!inside && !(s2 > qhi)) inside = sqrt(s2) < qmax;
-                if (inside) part += q->w;
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            if (lane == l) total += part;
-        }
-    }
-    const double expected = (maxDist * maxDist) / (cam.spw * cam.spw);
-    return total / expected;
-}
 
 // Diffuse + specular terms of one light at one hit (Solid.h:128-172), scaled by `kfac`
 // (Camera.h:465-476).  `rd` is the unit vector from the hit point to the light.
@@ -1273,7 +1272,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
                 dr->light = li;
                 dr->cam = defer_cam;
             } else if (want) {   // queue full: evaluate here
-                const double kfac = lc_calc_intensity(P.S.lc_table[defer_cam], Pt);
+                const double kfac = lc_calc_intensity(P.S.lc_table, defer_cam, Pt);
                 if (kfac > .01) { lit = true; local = phong_terms(P.S, hr, lt, unit3(sub3(lpos, Pt)), kfac); }
             }
         }
