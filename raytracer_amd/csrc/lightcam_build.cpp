@@ -69,8 +69,10 @@ int32_t build_node(Work &w, double lox, double loy, double loz, double size, int
         for (int32_t i = begin; i < end; ++i) w.perm[i] = w.scratch[i];
         nd.rest_begin = off[8];
         for (int k = 0; k < 8; ++k)
-            if (cnt[k] > 0)
+            if (cnt[k] > 0) {
                 nd.child[k] = build_node(w, clo[k][0], clo[k][1], clo[k][2], chi[k][0] - clo[k][0], off[k], off[k] + cnt[k]);
+                if ((*w.nodes)[nd.child[k]].leaf) nd.child_leaf |= 1 << k;
+            }
     }
     (*w.nodes)[me] = nd;
     return me;

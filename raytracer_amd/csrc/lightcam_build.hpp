@@ -13,15 +13,17 @@ struct Point {            // 32 bytes
 
 // One node of the point octree (Octree.h:1394-1497).  Its points are points[begin..end) of the
 // re-ordered point array; children keep the reference's octant order, -1 = no child.
-struct Node {             // 88 bytes
+struct Node {             // 96 bytes
     double cx, cy, cz, size;
     int32_t begin, end;
     int32_t leaf;         // the reference's `leaf` flag (true unless every point went to a child)
     int32_t child[8];
     int32_t rest_begin;   // points[rest_begin..end) belong to no child (all of the node's points when it has none)
     double wsum;          // sum of the weights of points[begin..end)
+    int32_t child_leaf;   // bit c: child c exists and its `leaf` flag is set
+    int32_t _pad;
 };
-static_assert(sizeof(Node) == 88, "lightcam::Node must be 88 bytes");
+static_assert(sizeof(Node) == 96, "lightcam::Node must be 96 bytes");
 
 struct Tree {
     std::vector<Node> nodes;     // node 0 = root

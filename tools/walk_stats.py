@@ -11,7 +11,7 @@ fn = C.CDLL(rt.LIB_PATH).rt_debug_counters
 fn.argtypes = [C.POINTER(C.c_ulonglong)]
 s = rt.Scene.load(scene_name); g = rt.Renderer(0); g.upload(s)
 cam = s.camera(resx, resy)
-buf = (C.c_ulonglong * 24)()
+buf = (C.c_ulonglong * 48)()
 fn(buf)
 fr = g.render(cam, num_samples=N, want=("rgb_u8",))
 fn(buf)
@@ -23,3 +23,13 @@ for gi, gname in enumerate(("primary", "queued", "shadow")):
     print("%-8s rays %11d | per ray: nodes %.2f leaves %.2f prims %.2f | per 64 rays the wave ran: node steps %.1f prim tests %.1f rounds %.1f"
           % (gname, v["rays"], v["lane_nodes"] / r, v["lane_leaves"] / r, v["lane_prims"] / r,
              v["wave_nodes"] * 64 / r, v["wave_prims"] * 64 / r, v["wave_rounds"] * 64 / r))
+q = list(buf[24:32])
+if q[0]:
+    n = q[0]
+    print("lightcam queries %d | per query: descent nodes %.1f, cells inside reached nodes %.1f (most for one query %d), whole-cell sums %.1f, "
+          "points tested %.1f (most for one query %d), ranges scanned by the wave: %d in all" % (n, q[1] / n, q[2] / n, q[7], q[3] / n, q[4] / n, q[6], q[5]))
+t = list(buf[32:40])
+if t[0]:
+    w = t[0]
+    print("lightcam waves %d | per wave: %.0f ticks (100 MHz clock) in the query, %.0f of them in %.1f cooperative phases, slowest lane %.1f trips | "
+          "longest wave %d ticks, %d trips" % (w, t[1] / w, t[2] / w, t[4] / w, t[3] / w, t[5], t[6]))
