@@ -76,7 +76,10 @@ struct alignas(16) HitRec {      // 128 bytes
     uint32_t pixel;
     int32_t prim;                // the solid that was hit (never occludes itself)
     int32_t light, cam;          // only in the deferred light-camera queue: light index, camera index
+    int32_t mat;                 // material index of `prim`
+    int32_t _pad;
 };
+static_assert(sizeof(HitRec) == 128, "HitRec must be 128 bytes");
 
 struct DevScene {
     const rt_node *nodes;
@@ -100,6 +103,8 @@ struct DevScene {
     int32_t n_tri_nodes, n_sph_nodes;
     int32_t tri_cached, sph_cached;       // the first so many nodes of each hierarchy are copied into LDS by every block
     int32_t lds_cache_word;               // first LDS word of the node cache (after the traversal stacks)
+    int32_t mat_cached, light_cached;     // the first so many materials / lights are copied into LDS as well
+    int32_t lds_table_word;               // first LDS word of those tables (materials, then lights; 16 words each)
     float bvh_bound;                      // largest |coordinate| of any hierarchy box
     // light cameras (LightCam.h): one per (transparent sphere, light) pair, index rank*n_lights+light
     const int32_t *prim_lc_rank;          // per primitive: rank among transparent spheres, or -1
@@ -432,17 +437,53 @@ DEV int leaf_count(int code) { return ((-2 - code) & 3) + 1; }
 // occupies 36 words instead of 32: with a stride of 32 every node would start in the same bank.
 extern __shared__ __align__(16) int s_lds[];
 #define NODE_LDS_WORDS 36
-DEV void fill_node_cache(const DevScene &S)
+DEV void fill_node_cache(const DevScene &S, bool with_nodes)
 {
-    const int words = (S.tri_cached + S.sph_cached) * 32;
-    const int *tsrc = reinterpret_cast<const int *>(S.tri_nodes);
-    const int *ssrc = reinterpret_cast<const int *>(S.sph_nodes);
-    for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) {
-        const int node = i >> 5, w = i & 31;
-        const int v = node < S.tri_cached ? tsrc[i] : ssrc[i - S.tri_cached * 32];
-        s_lds[S.lds_cache_word + node * NODE_LDS_WORDS + w] = v;
+    if (with_nodes) {
+        const int words = (S.tri_cached + S.sph_cached) * 32;
+        const int *tsrc = reinterpret_cast<const int *>(S.tri_nodes);
+        const int *ssrc = reinterpret_cast<const int *>(S.sph_nodes);
+        for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) {
+            const int node = i >> 5, w = i & 31;
+            const int v = node < S.tri_cached ? tsrc[i] : ssrc[i - S.tri_cached * 32];
+            s_lds[S.lds_cache_word + node * NODE_LDS_WORDS + w] = v;
+        }
     }
+    // material and light tables (64 bytes per entry): every hit reads one of each, always the same few
+    const int mwords = S.mat_cached * 16, lwords = S.light_cached * 16;
+    const int *msrc = reinterpret_cast<const int *>(S.materials);
+    const int *lsrc = reinterpret_cast<const int *>(S.lights);
+    for (int i = (int)threadIdx.x; i < mwords + lwords; i += (int)blockDim.x)
+        s_lds[S.lds_table_word + i] = i < mwords ? msrc[i] : lsrc[i - mwords];
     __syncthreads();
+}
+
+// A 64-byte table entry (rt_material or rt_light) from LDS when it is cached there, else from memory.
+template <typename T>
+DEV T load_entry(const T *table, int index, int cached, int lds_word)
+{
+    static_assert(sizeof(T) == 64, "table entries are 64 bytes");
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    union { v4i q[4]; T e; } u;
+    if (index < cached) {
+        const __attribute__((address_space(3))) v4i *p =
+            (const __attribute__((address_space(3))) v4i *)((__attribute__((address_space(3))) const int *)s_lds + (lds_word + index * 16));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u.q[k] = p[k];
+    } else {
+        const __attribute__((address_space(1))) v4i *p = (const __attribute__((address_space(1))) v4i *)(table + index);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u.q[k] = p[k];
+    }
+    return u.e;
+}
+DEV rt_material load_material(const DevScene &S, int index, bool lds)
+{
+    return load_entry(S.materials, index, lds ? S.mat_cached : 0, S.lds_table_word);
+}
+DEV rt_light load_light(const DevScene &S, int index, bool lds)
+{
+    return load_entry(S.lights, index, lds ? S.light_cached : 0, S.lds_table_word + S.mat_cached * 16);
 }
 
 // Single-precision view of a ray for the slab tests.  A child box passes when the ray's
@@ -598,6 +639,7 @@ struct Best {
     double t;
     int key;      // tie-break: position in the reference's visiting order
     int slot;     // record index | SLOT_SPHERE
+    int prim;     // primitive id of that record
 };
 
 // Nearest hit over one hierarchy.  TRI selects the leaf record type.  Two phases per round:
@@ -624,13 +666,14 @@ DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb
         const int b = leaf_begin(cur), e = b + leaf_count(cur);
         for (int k = b; k < e; ++k) {
             double t;
-            int key;
+            int key, prim = -1;
             WC_ADD(wc, lane_prims);
             WC_WAVE(wc, wave_prims);
-            if (TRI) { const TriOps tr = load_tri(&S.btri[k]); t = tri_test_fast(tr, o, d, minT, maxT, best.t); key = tr.key; }
+            if (TRI) { const TriOps tr = load_tri(&S.btri[k]); t = tri_test_fast(tr, o, d, minT, maxT, best.t); key = tr.key; prim = tr.prim; }
             else { t = sph_test(&S.bsph[k], o, d, d2, minT, maxT); key = S.bsph_key[k]; }
             if (t < best.t || (t == best.t && t < maxT && key < best.key)) {
                 best.t = t; best.key = key; best.slot = TRI ? k : (k | SLOT_SPHERE);
+                best.prim = TRI ? prim : (int)(S.bsph_prim[k] & ~RT_SPH_TRANSPARENT);
             }
         }
         if (sp == 0) break;
@@ -702,18 +745,19 @@ DEV bool root_gate(const DevScene &S, d3 o, d3 d, double d2, double sentinel)
 // Geometry of a found hit (Solid.h:110-125): primitive id, unit normal, impact point.
 // `best` is a slot of the given record arrays (| SLOT_SPHERE for spheres).
 DEV void hit_geometry(const DevScene &S, const rt_tri_rec *tri_arr, const rt_sph_rec *sph_arr, const uint32_t *sph_prim_arr,
-                      uint32_t flags, d3 o, d3 d, double minT, double t, int best, int *prim_out, d3 *n_out, d3 *P_out)
+                      uint32_t flags, d3 o, d3 d, double minT, double t, int best, int known_prim, int *prim_out, d3 *n_out,
+                      d3 *P_out)
 {
     d3 nraw;
-    int prim;
+    int prim = known_prim;       // >= 0: the walk already knows it, no need to go through the record
     if (best & SLOT_SPHERE) {
         const int s = best & ~SLOT_SPHERE;
-        prim = (int)(sph_prim_arr[s] & ~RT_SPH_TRANSPARENT);
+        if (known_prim < 0) prim = (int)(sph_prim_arr[s] & ~RT_SPH_TRANSPARENT);
         const rt_sph_rec *sp = &sph_arr[s];
         nraw = div3(sub3(add3(o, scale3(t, d)), ld3(sp->center)), sp->radius);
     } else {
         const rt_tri_rec *tr = &tri_arr[best];
-        prim = tr->prim;
+        if (known_prim < 0) prim = tr->prim;
         const double *pn = &S.prim_normals[(size_t)prim * 12];
         nraw = ld3(pn);
         if ((flags & RT_FLAG_PHONG_NORMALS) && (S.prim_flags[prim] & RT_PRIM_HAS_VNORMALS)) {
@@ -1089,7 +1133,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
 {
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
-    if (BVH) fill_node_cache(P.S);
+    fill_node_cache(P.S, BVH);
     const int lane = (int)(threadIdx.x & 63);
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
@@ -1174,12 +1218,12 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
         }
 
         double best_t = 0;
-        int best = -1;
+        int best = -1, best_prim = -1;
         if (active) {
             if (BVH) {
                 const double d2 = dot3(d, d);
                 Best bst;
-                bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1;
+                bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1; bst.prim = -1;
                 if (root_gate(P.S, o, d, d2, 10000000000.0)) {
                     const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
                     WC_ADD(wc, rays);
@@ -1188,6 +1232,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
                 }
                 best_t = bst.t;
                 best = bst.slot;
+                best_prim = bst.prim;
             } else {
                 trace_closest(P.S, o, d, cull, .01, best_t, best);
             }
@@ -1204,13 +1249,14 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
 
         // hit record (Solid.h:110-125)
         d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0), refl = mk3(0, 0, 0);
-        int prim = -1;
+        int prim = -1, mat = 0;
         rt_material m;
         m.Ks = 0; m.T = 0; m.ior = 1;
         if (hit) {
-            hit_geometry(P.S, tri_arr, sph_arr, sph_prim_arr, P.flags, o, d, .01, best_t, best, &prim, &n, &Pt);
+            hit_geometry(P.S, tri_arr, sph_arr, sph_prim_arr, P.flags, o, d, .01, best_t, best, best_prim, &prim, &n, &Pt);
             refl = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));
-            m = P.S.materials[P.S.prim_material[prim]];
+            mat = P.S.prim_material[prim];
+            m = load_material(P.S, mat, true);
         }
         if (PRIMARY && active && first_sample && P.hit_id) P.hit_id[pixel] = prim;
 
@@ -1252,6 +1298,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
             h->weight = wloc;
             h->pixel = pixel;
             h->prim = prim;
+            h->mat = mat;
         }
         if (want_refr && slot_a < Q.out_shard_cap) {
             const d3 rd = refract_dir(d, n, m.ior, false);
@@ -1281,9 +1328,8 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
 
 // Diffuse + specular terms of one light at one hit (Solid.h:128-172), scaled by `kfac`
 // (Camera.h:465-476).  `rd` is the unit vector from the hit point to the light.
-DEV d3 phong_terms(const DevScene &S, const HitRec *hr, const rt_light *lt, d3 rd, double kfac)
+DEV d3 phong_terms(const rt_material &m, const HitRec *hr, const rt_light *lt, d3 rd, double kfac)
 {
-    const rt_material m = S.materials[S.prim_material[hr->prim]];
     const d3 normal = ld3(hr->n);
     d3 local = mk3(0, 0, 0);
     if (m.Ks > 0) {
@@ -1314,7 +1360,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
 {
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
-    if (BVH) fill_node_cache(P.S);
+    fill_node_cache(P.S, BVH);
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     const uint32_t nl = (uint32_t)P.S.n_lights;
@@ -1329,9 +1375,8 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
         const uint32_t h = active ? (uint32_t)item / nl : 0u;
         const int li = active ? (int)((uint32_t)item - h * nl) : 0;
         const HitRec *hr = &Q.hits[(size_t)shard * Q.hit_shard_cap + h];
-        const rt_light *lt = &P.S.lights[li];
         const d3 Pt = ld3(hr->P);
-        const d3 lpos = ld3(lt->pos);
+        const d3 lpos = ld3(load_light(P.S, li, true).pos);
         const uint32_t pixel = hr->pixel;
         bool lit = false;
         int defer_cam = -1;
@@ -1370,7 +1415,10 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
                 }
             }
             lit = !occluded;
-            if (lit) local = phong_terms(P.S, hr, lt, rd, .999999);
+            if (lit) {
+                const rt_light lgt = load_light(P.S, li, true);     // read again here rather than kept in registers through the walk
+                local = phong_terms(load_material(P.S, hr->mat, true), hr, &lgt, rd, .999999);
+            }
         }
         if (!BVH && P.S.lc_table) {
             bool ok;
@@ -1383,7 +1431,11 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
                 dr->cam = defer_cam;
             } else if (want) {   // queue full: evaluate here
                 const double kfac = lc_calc_intensity(P.S.lc_table, defer_cam, Pt);
-                if (kfac > .01) { lit = true; local = phong_terms(P.S, hr, lt, unit3(sub3(lpos, Pt)), kfac); }
+                if (kfac > .01) {
+                    lit = true;
+                    const rt_light lgt = load_light(P.S, li, true);
+                    local = phong_terms(load_material(P.S, hr->mat, true), hr, &lgt, unit3(sub3(lpos, Pt)), kfac);
+                }
             }
         }
         accum_add_runs(P.accum, active, lit, pixel, hr->weight, local);
@@ -1422,7 +1474,7 @@ __global__ __launch_bounds__(256) void k_lightcam(FrameParams P, QueueSet Q)
             const rt_light *lt = &P.S.lights[hr->light];
             if (kfac > .01) {
                 lit = true;
-                local = phong_terms(P.S, hr, lt, unit3(sub3(ld3(lt->pos), Pt)), kfac);
+                local = phong_terms(load_material(P.S, hr->mat, false), hr, lt, unit3(sub3(ld3(lt->pos), Pt)), kfac);
             }
         }
         accum_add_runs(P.accum, active, lit, hr->pixel, hr->weight, local);
@@ -1481,7 +1533,7 @@ __global__ __launch_bounds__(256) void k_photons(PhotonParams Q)
         if (best < 0) break;
         int prim;
         d3 n, Pt;
-        hit_geometry(Q.S, Q.S.tri, Q.S.sph, Q.S.sph_prim, Q.flags, o, d, .000001, t, best, &prim, &n, &Pt);
+        hit_geometry(Q.S, Q.S.tri, Q.S.sph, Q.S.sph_prim, Q.flags, o, d, .000001, t, best, -1, &prim, &n, &Pt);
         const rt_material m = Q.S.materials[Q.S.prim_material[prim]];
         lightcam::Point pt;
         pt.x = Pt.x; pt.y = Pt.y; pt.z = Pt.z;
@@ -1581,6 +1633,7 @@ struct rt_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_shadow;
     size_t ev_closest_used = 0, ev_shadow_used = 0;
     int cu_count = 256;
+    int32_t n_materials = 0;
     size_t lds_per_cu = 64 * 1024;   // LDS of one compute unit (maxSharedMemoryPerMultiProcessor)
 };
 
@@ -1801,6 +1854,7 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     D.bg[0] = s->background[0]; D.bg[1] = s->background[1]; D.bg[2] = s->background[2];
     ctx->S = D;
     ctx->lightcam_samples = s->lightcam_samples;
+    ctx->n_materials = s->n_materials;
     ctx->any_transparent = false;
     for (int32_t i = 0; i < s->n_materials; ++i) if (s->materials[i].T > 0) ctx->any_transparent = true;
     ctx->any_transparent_sphere = false;
@@ -2014,12 +2068,16 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     int stack_entries = 3 * ctx->accel_depth + 1;
     if (stack_entries > BVH_STACK) stack_entries = BVH_STACK;
     if (stack_entries < 4) stack_entries = 4;
-    // LDS per block: the stacks, then as many top-of-tree nodes as fit beside them when four blocks
-    // share a compute unit (the register budget allows four waves per SIMD)
+    // LDS per block: the stacks, the material and light tables, then as many top-of-tree nodes as fit
+    // beside them when four blocks share a compute unit (the register budget allows four waves per SIMD)
     const size_t lds_stack = (size_t)stack_entries * 256 * sizeof(int);
+    P.S.mat_cached = ctx->n_materials < 64 ? ctx->n_materials : 64;
+    P.S.light_cached = P.S.n_lights < 16 ? P.S.n_lights : 16;
+    const size_t lds_tables = (size_t)(P.S.mat_cached + P.S.light_cached) * 64;
     {
         const size_t per_block = ctx->lds_per_cu / 4;
-        long long room = per_block > lds_stack + 512 ? (long long)((per_block - lds_stack - 512) / (NODE_LDS_WORDS * 4)) : 0;
+        const size_t fixed = lds_stack + lds_tables + 512;
+        long long room = per_block > fixed ? (long long)((per_block - fixed) / (NODE_LDS_WORDS * 4)) : 0;
         if (const char *e = std::getenv("RT_NODE_CACHE")) room = std::atoll(e) < room ? std::atoll(e) : room;   // experiments
         // the triangle hierarchy first, the sphere hierarchy takes what is left; split evenly when both are large
         long long nt = P.S.n_tri_nodes, ns = P.S.n_sph_nodes;
@@ -2032,10 +2090,12 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         P.S.tri_cached = (int32_t)nt;
         P.S.sph_cached = (int32_t)ns;
         P.S.lds_cache_word = (int32_t)(lds_stack / sizeof(int));
+        P.S.lds_table_word = P.S.lds_cache_word + (P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS;
     }
-    const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int);
-    const size_t lds_closest = bvh_closest_ok ? lds_bvh : 0;
-    const size_t lds_shadow = bvh_shadow_ok ? lds_bvh : 0;
+    // every traversal kernel gets the same layout (the octree-walk variants use the tables only)
+    const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int) + lds_tables;
+    const size_t lds_closest = lds_bvh;
+    const size_t lds_shadow = lds_bvh;
 
     hipStream_t st = ctx->stream;
     HIP_TRY(hipEventRecord(ctx->ev_begin, st));
@@ -2155,10 +2215,10 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     long long blocks = (t1 - t0 + 3) / 4;
                     if (blocks > blocks0) blocks = blocks0;
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(256), lds_closest, st, P, Q);
-                    else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q);
+                    else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(256), lds_closest, st, P, Q);
                 } else {
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<false, true>), dim3((unsigned)max_blocks), dim3(256), lds_closest, st, P, Q);
-                    else hipLaunchKernelGGL((k_closest<false, false>), dim3((unsigned)max_blocks), dim3(256), 0, st, P, Q);
+                    else hipLaunchKernelGGL((k_closest<false, false>), dim3((unsigned)max_blocks), dim3(256), lds_closest, st, P, Q);
                 }
                 if (ev) HIP_TRY(hipEventRecord(ev->second, st));
                 HIP_TRY(hipEventRecord(ctx->ev_c[g], st));
@@ -2169,7 +2229,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                         return fail(RT_ERR_DEVICE, "hipEventCreate failed");
                     if (ev) HIP_TRY(hipEventRecord(ev->first, sb));
                     if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
-                    else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(256), 0, sb, P, Q);
+                    else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
                     if (use_lightcam) hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks), dim3(256), 0, sb, P, Q);
                     if (ev) HIP_TRY(hipEventRecord(ev->second, sb));
                     HIP_TRY(hipEventRecord(ctx->ev_s[g], sb));
