@@ -178,6 +178,18 @@ int rt_sync(rt_ctx *ctx, rt_stats *stats);
 /* Primary batch size (primary samples per pipeline pass); 0 restores the default. */
 int rt_set_batch(rt_ctx *ctx, int64_t primaries);
 
+/* Diagnostic: runs the kernels' own primitive tests on n (primitive, ray) pairs, one per GPU thread, so that
+ * each can be compared with the reference's function in isolation.
+ *   kind 0: Triangle::intersect (Triangle.h:91-158), the plain sequence of three divisions;
+ *   kind 1: the same test in the form the traversal uses (rejections decided before dividing);
+ *   kind 2: Sphere::intersect (Sphere.h:35-77), and the hit record's normal (Solid.h:119);
+ *   kind 3: the node bounding-sphere test (Sphere.h:155-204), `maxT` being the sentinel it returns on a miss.
+ * geom: 9 doubles per item (v0, v1, v2) for kinds 0/1, 4 doubles (centre, radius) for kinds 2/3.
+ * rays: 6 doubles per item (origin, direction).  out: 4 doubles per item: t (or maxT), then the unit normal
+ * for a sphere hit, else zeros.  All pointers are host memory. */
+int rt_debug_intersect(rt_ctx *ctx, int32_t kind, int32_t n, const double *geom, const double *rays, double minT,
+                       double maxT, double *out);
+
 /* ---- host front end ---- */
 /* Parses an .nff file (dialect of Driver.cpp:426-691), ear-clips polygons and patches
  * (Polygon.h:107-205, PolygonalPatch.h:78-157), builds and flattens the octree. */

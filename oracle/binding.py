@@ -53,6 +53,7 @@ def load():
     lib.orc_test_sphere.argtypes = [dp, C.c_double, dp, dp, C.c_double, C.c_double, dp]
     lib.orc_test_bound.restype = C.c_double
     lib.orc_test_bound.argtypes = [dp, C.c_double, dp, dp, C.c_double, C.c_double]
+    lib.orc_test_batch.argtypes = [C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, dp]
     lib.orc_lightcam_count.restype = C.c_int
     lib.orc_lightcam_count.argtypes = [C.c_void_p]
     lib.orc_lightcam_info.argtypes = [C.c_void_p, C.c_int, ip, ip, ip, C.POINTER(C.c_uint64)]
@@ -187,3 +188,13 @@ def test_bound(c3, r, d, e, min_t, max_t):
     d = np.ascontiguousarray(d, dtype=np.float64)
     e = np.ascontiguousarray(e, dtype=np.float64)
     return load().orc_test_bound(_dp(c3), r, _dp(d), _dp(e), min_t, max_t)
+
+
+def test_batch(kind, geom, rays, min_t, max_t):
+    """kind 0 triangle (geom n x 9), 2 sphere (n x 4), 3 node bound (n x 4); rays n x 6 (origin, direction).
+    Returns n x 4: t, then the hit record's unit normal (zero on a miss and for kind 3)."""
+    geom = np.ascontiguousarray(geom, dtype=np.float64)
+    rays = np.ascontiguousarray(rays, dtype=np.float64)
+    out = np.zeros((len(rays), 4))
+    load().orc_test_batch(kind, len(rays), _dp(geom), _dp(rays), min_t, max_t, _dp(out))
+    return out

@@ -1333,6 +1333,26 @@ double orc_test_bound(const double *c3, double radius, const double *d3, const d
     return bound_intersect(V(c3[0], c3[1], c3[2]), radius, V(d3[0], d3[1], d3[2]), V(e3[0], e3[1], e3[2]), minT, maxT);
 }
 
+/* The same three tests for n items at once.  kind 0: triangle (geom: 9 doubles v0 v1 v2), 2: sphere (geom: centre,
+ * radius), 3: node bounding sphere (geom: centre, radius).  rays: 6 doubles per item (origin, direction).
+ * out: 4 doubles per item: the returned t, then the unit normal stored in the hit record (zero on a miss / kind 3). */
+void orc_test_batch(int kind, int n, const double *geom, const double *rays, double minT, double maxT, double *out)
+{
+    for (int i = 0; i < n; i++) {
+        const double *e = rays + (size_t)i * 6, *d = e + 3;
+        double o7[7] = {0, 0, 0, 0, 0, 0, 0};
+        double t;
+        if (kind == 0) t = orc_test_triangle(geom + (size_t)i * 9, NULL, 0, d, e, minT, maxT, o7);
+        else if (kind == 2) t = orc_test_sphere(geom + (size_t)i * 4, geom[(size_t)i * 4 + 3], d, e, minT, maxT, o7);
+        else t = orc_test_bound(geom + (size_t)i * 4, geom[(size_t)i * 4 + 3], d, e, minT, maxT);
+        out[(size_t)i * 4] = t;
+        const int hit = kind != 3 && t < maxT;
+        out[(size_t)i * 4 + 1] = hit ? o7[1] : 0;
+        out[(size_t)i * 4 + 2] = hit ? o7[2] : 0;
+        out[(size_t)i * 4 + 3] = hit ? o7[3] : 0;
+    }
+}
+
 /* light-camera introspection: number of cameras built so far and their sizes */
 int orc_lightcam_count(const Scene *s) { return s->ncams; }
 void orc_lightcam_info(const Scene *s, int i, int *sphere, int *light, int *npts, uint64_t *rays)

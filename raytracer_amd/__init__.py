@@ -117,6 +117,8 @@ _SIGNATURES = {
     "rt_render_async": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.POINTER(FrameOut)]),
     "rt_sync": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rt_set_batch": (C.c_int, [C.c_void_p, C.c_int64]),
+    "rt_debug_intersect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.c_double, C.c_double, C.POINTER(C.c_double)]),
     "rth_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "rth_scene_free": (C.c_int, [C.c_void_p]),
     "rth_scene_desc": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
@@ -351,6 +353,16 @@ class Renderer:
         if sync:
             return self.sync()
         return None
+
+    def debug_intersect(self, kind, geom, rays, min_t, max_t):
+        """Runs the device's primitive tests on (primitive, ray) pairs; see rt_debug_intersect.  Returns n x 4."""
+        geom = np.ascontiguousarray(geom, dtype=np.float64)
+        rays = np.ascontiguousarray(rays, dtype=np.float64)
+        out = np.zeros((len(rays), 4))
+        dp = C.POINTER(C.c_double)
+        _check(load().rt_debug_intersect(self._ctx, kind, len(rays), geom.ctypes.data_as(dp), rays.ctypes.data_as(dp),
+                                         min_t, max_t, out.ctypes.data_as(dp)))
+        return out
 
     def sync(self):
         stats = Stats()

@@ -1744,6 +1744,67 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     return RT_OK;
 }
 
+// One primitive test per thread with the device functions the kernels use (rt_debug_intersect).
+__global__ void k_debug_intersect(int kind, int n, const double *geom, const double *rays, double minT, double maxT, double *out)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const d3 o = ld3(rays + (size_t)i * 6), d = ld3(rays + (size_t)i * 6 + 3);
+    double t = maxT;
+    d3 nrm = mk3(0, 0, 0);
+    if (kind == 0 || kind == 1) {
+        const double *g = geom + (size_t)i * 9;
+        rt_tri_rec tr;
+        for (int k = 0; k < 3; ++k) { tr.v0[k] = g[k]; tr.ab[k] = g[k] - g[3 + k]; tr.ac[k] = g[k] - g[6 + k]; }   // Triangle.h:40-46
+        tr.prim = 0; tr._pad0 = 0; tr._pad1[0] = tr._pad1[1] = 0;
+        if (kind == 0) { double al, be; t = tri_test(&tr, o, d, minT, maxT, &al, &be); }
+        else {
+            TriOps ops;
+            ops.v0 = ld3(tr.v0); ops.ab = ld3(tr.ab); ops.ac = ld3(tr.ac); ops.prim = 0; ops.key = 0;
+            t = tri_test_fast(ops, o, d, minT, maxT, maxT);
+        }
+    } else if (kind == 2) {
+        const double *g = geom + (size_t)i * 4;
+        rt_sph_rec sp;
+        sp.center[0] = g[0]; sp.center[1] = g[1]; sp.center[2] = g[2]; sp.radius = g[3];
+        t = sph_test(&sp, o, d, dot3(d, d), minT, maxT);
+        if (t < maxT) nrm = unit3(div3(sub3(add3(o, scale3(t, d)), ld3(sp.center)), sp.radius));
+    } else {
+        const double *g = geom + (size_t)i * 4;
+        rt_node nd;
+        nd.center[0] = g[0]; nd.center[1] = g[1]; nd.center[2] = g[2]; nd.radius = g[3];
+        double entry;
+        t = bound_test(&nd, o, d, dot3(d, d), minT, maxT, &entry);
+    }
+    out[(size_t)i * 4] = t; out[(size_t)i * 4 + 1] = nrm.x; out[(size_t)i * 4 + 2] = nrm.y; out[(size_t)i * 4 + 3] = nrm.z;
+}
+
+extern "C" int rt_debug_intersect(rt_ctx *ctx, int32_t kind, int32_t n, const double *geom, const double *rays, double minT,
+                                  double maxT, double *out)
+{
+    if (!ctx || !geom || !rays || !out || n < 0 || kind < 0 || kind > 3) return fail(RT_ERR_INVALID, "rt_debug_intersect: bad argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t gdoubles = (size_t)n * (kind <= 1 ? 9 : 4);
+    double *d_geom = nullptr, *d_rays = nullptr, *d_out = nullptr;
+    int rc = RT_OK;
+    if (hipMalloc((void **)&d_geom, gdoubles * 8) != hipSuccess || hipMalloc((void **)&d_rays, (size_t)n * 48) != hipSuccess ||
+        hipMalloc((void **)&d_out, (size_t)n * 32) != hipSuccess)
+        rc = fail(RT_ERR_DEVICE, "rt_debug_intersect: hipMalloc failed");
+    if (rc == RT_OK && (hipMemcpy(d_geom, geom, gdoubles * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(d_rays, rays, (size_t)n * 48, hipMemcpyHostToDevice) != hipSuccess))
+        rc = fail(RT_ERR_DEVICE, "rt_debug_intersect: upload failed");
+    if (rc == RT_OK) {
+        hipLaunchKernelGGL(k_debug_intersect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)kind, (int)n,
+                           d_geom, d_rays, minT, maxT, d_out);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+            hipMemcpy(out, d_out, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(RT_ERR_DEVICE, "rt_debug_intersect: kernel or download failed");
+    }
+    (void)hipFree(d_geom); (void)hipFree(d_rays); (void)hipFree(d_out);
+    return rc;
+}
+
 #ifdef RT_COUNT
 // Diagnostic builds: totals since the last call: 3 groups (primary, queued closest, shadow) x 8 words,
 // then 8 words of the light-camera queries.
