@@ -63,7 +63,8 @@ def build_library(force=False):
     deps += [lc_src, lc_hdr]
     if force or _newer(lc_obj, [lc_src, lc_hdr, os.path.abspath(__file__)]):
         _run(["g++"] + HOST_FLAGS + ["-c", lc_src, "-o", lc_obj])
-    if force or _newer(dev_obj, [dev_src, header, accel_hdr, lc_hdr, os.path.abspath(__file__)]):
+    dev_hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")]
+    if force or _newer(dev_obj, [dev_src, header, os.path.abspath(__file__)] + dev_hdrs):
         _run([hipcc] + DEVICE_FLAGS + ["-c", dev_src, "-o", dev_obj])
     if force or _newer(host_obj, [host_src, header, os.path.join(CSRC, "host_scene.hpp"), os.path.abspath(__file__)]):
         _run(["g++"] + HOST_FLAGS + ["-c", host_src, "-o", host_obj])

@@ -1,0 +1,108 @@
+// Records and parameter blocks shared by the kernels of the render path: what lives in HBM
+// (ray and hit queues, the scene tables, the light-camera trees) and what a launch is handed.
+#pragma once
+#include <cstdint>
+
+#include "../../include/raytracer_amd.h"
+#include "accel_build.hpp"
+#include "lightcam_build.hpp"
+
+struct alignas(16) RayRec {      // 80 bytes
+    double o[3];
+    double d[3];
+    double A;                    // product of T along the chain of refraction calls
+    double coef;                 // coefOfReflection carried by the call (Camera.h:241,305)
+    uint32_t pixel;              // local pixel index
+    uint32_t meta;               // bits 0..7: remaining loop iterations, bit 8: first ray of a call
+    uint32_t _pad[2];
+};
+
+struct alignas(16) HitRec {      // 128 bytes
+    double P[3];                 // impactPos
+    double n[3];                 // hr.normal normalised a second time, as computeLocalColor does (Camera.h:382)
+    double nn[3];                // ... and a third time, as computeSpecularComp does (Solid.h:153)
+    double v[3];                 // unit vector from the hit point to the ray origin (Solid.h:156)
+    double weight;               // factor applied to the local colour
+    uint32_t pixel;
+    int32_t prim;                // the solid that was hit (never occludes itself)
+    int32_t light, cam;          // only in the deferred light-camera queue: light index, camera index
+    int32_t mat;                 // material index of `prim`
+    int32_t _pad;
+};
+static_assert(sizeof(HitRec) == 128, "HitRec must be 128 bytes");
+
+struct DevScene {
+    const rt_node *nodes;
+    const rt_tri_rec *tri;
+    const rt_sph_rec *sph;
+    const uint32_t *sph_prim;
+    const uint32_t *prim_flags;
+    const int32_t *prim_material;
+    const double *prim_normals;
+    const rt_material *materials;
+    const rt_light *lights;
+    int32_t n_nodes, n_lights;
+    double bg[3];
+    // derived hierarchies (accel_build.hpp); leaf records share the layout of the octree slots
+    const accel::Bvh4Node *tri_nodes;
+    const rt_tri_rec *btri;
+    const accel::Bvh4Node *sph_nodes;
+    const rt_sph_rec *bsph;
+    const uint32_t *bsph_prim;
+    const int32_t *bsph_key;
+    int32_t n_tri_nodes, n_sph_nodes;
+    int32_t tri_cached, sph_cached;       // the first so many nodes of each hierarchy are copied into LDS by every block
+    int32_t lds_cache_word;               // first LDS word of the node cache (after the traversal stacks)
+    int32_t mat_cached, light_cached;     // the first so many materials / lights are copied into LDS as well
+    int32_t lds_table_word;               // first LDS word of those tables (materials, then lights; 16 words each)
+    float bvh_bound;                      // largest |coordinate| of any hierarchy box
+    // light cameras (LightCam.h): one per (transparent sphere, light) pair, index rank*n_lights+light
+    const int32_t *prim_lc_rank;          // per primitive: rank among transparent spheres, or -1
+    const struct DevLightCam *lc_table;   // null until the cameras are built
+};
+
+struct DevLightCam {
+    const lightcam::Node *nodes;
+    const lightcam::Point *points;
+    int32_t n_nodes, n_points;
+    double spw;                           // sub-pixel width of the light camera (LightCam.h:223)
+    double light_pos[3], sphere_pos[3];
+};
+
+struct FrameParams {
+    DevScene S;
+    rt_camera cam;
+    int32_t N;                   // samples per axis
+    double aperture;
+    uint32_t flags, seed;
+    int32_t band_rows, n_parts, part, local_rows;
+    int32_t blocks_x;            // 8x8-pixel blocks per row of blocks (primary sample ordering)
+    int32_t cull_closest, cull_shadow;
+    double *accum;               // local_rows*resx*3
+    int32_t *hit_id;             // local_rows*resx or null
+    uint8_t *lc_mask;            // local_rows*resx or null
+};
+
+// Queues are cut into N_SHARDS independent shards (a block pushes into shard blockIdx % N_SHARDS),
+// so that no single counter word serialises the pushes of the whole chip; a consumer walks the
+// shards' 64-ray chunks as one list.
+#define N_SHARDS 64
+#define CNT_RAYS(g) ((g) * N_SHARDS)             // g = 0..6
+#define CNT_HITS(g) ((7 + (g)) * N_SHARDS)       // g = 0..5
+#define CNT_DEFER(g) ((13 + (g)) * N_SHARDS)     // g = 0..5: deferred light-camera evaluations
+#define CNT_OVERFLOW (19 * N_SHARDS)
+#define CNT_WORDS (19 * N_SHARDS + 16)
+
+struct QueueSet {
+    RayRec *rays_in;
+    RayRec *rays_out;
+    HitRec *hits;
+    HitRec *deferred;            // light-camera evaluations postponed by the shadow pass (same shard size as hits)
+    uint32_t *counts;
+    uint32_t in_shard_cap, out_shard_cap, hit_shard_cap;   // records per shard
+    int32_t generation;
+    int64_t chunk_begin, chunk_end;  // PRIMARY only: 64-sample chunks of the primary ordering
+};
+
+// A found primitive is named by its record slot: a triangle slot, or a sphere slot with this bit set.
+#define SLOT_SPHERE 0x40000000

@@ -1,0 +1,122 @@
+// The reference's ray-primitive tests, operation for operation: node bounding sphere
+// (Sphere.h:155-204), triangle (Triangle.h:91-158), sphere (Sphere.h:35-77).
+#pragma once
+#include "device_math.hpp"
+#include "device_records.hpp"
+
+// Bounding-sphere test of a node (Sphere.h:155-204).  Returns the value the reference
+// returns (t2, t1 or `sentinel`).  The reference takes sqrt(B*B-4AC) without halving it, so
+// its roots are wider than the sphere's; *entry receives the true distance at which the
+// ray enters the sphere, (-b - root/2)/A, which is what pruning may compare against.
+DEV double bound_test(const rt_node *nd, d3 o, d3 d, double A, double minT, double sentinel, double *entry)
+{
+    d3 emp = sub3(o, ld3(nd->center));
+    double r = nd->radius;
+    double C = dot3(emp, emp) - r * r;
+    double B = 2.0 * dot3(d, emp);
+    double disc = B * B - 4 * A * C;
+    *entry = sentinel;
+    if (disc < 0) return sentinel;
+    double b = B / 2;
+    double root = sqrt(disc);
+    double t1 = (-b + root) / A;
+    double t2 = (-b - root) / A;
+    *entry = (-b - 0.5 * root) / A;
+    if (t2 > minT) return t2;
+    else if (t1 > minT) return t1;
+    return sentinel;
+}
+
+// Triangle::intersect (Triangle.h:91-158) without the hit-record update; returns t or maxT.
+DEV double tri_test(const rt_tri_rec *tr, d3 o, d3 d, double minT, double maxT, double *alpha_out, double *beta_out)
+{
+    d3 v0 = ld3(tr->v0), ab = ld3(tr->ab), ac = ld3(tr->ac);
+    d3 ae = sub3(v0, o);
+    double detA = det3(ab, ac, d);
+    double alpha = det3(ae, ac, d) / detA;
+    if (alpha < 0 || alpha > 1) return maxT;
+    double beta = det3(ab, ae, d) / detA;
+    if (beta < 0 || beta > 1 - alpha) return maxT;
+    double t = det3(ab, ac, ae) / detA;
+    if (t < minT || t > maxT) return maxT;
+    *alpha_out = alpha;
+    *beta_out = beta;
+    return t;
+}
+
+// Operands of one triangle test, fetched as five 16-byte loads (the first 80 bytes of the record:
+// v0, ab, ac, primitive id, tie key).  The memory pipeline spends the same time on a one-word load
+// of a wave as on a four-word one, so the number of load instructions is what counts.
+struct TriOps {
+    d3 v0, ab, ac;
+    int prim, key;
+};
+DEV TriOps load_tri(const rt_tri_rec *tr)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const __attribute__((address_space(1))) v2d *p = (const __attribute__((address_space(1))) v2d *)tr;
+    const v2d a = p[0], b = p[1], c = p[2], e = p[3], f = p[4];
+    TriOps t;
+    t.v0 = mk3(a.x, a.y, b.x);
+    t.ab = mk3(b.y, c.x, c.y);
+    t.ac = mk3(e.x, e.y, f.x);
+    t.prim = __double2loint(f.y);
+    t.key = __double2hiint(f.y);
+    return t;
+}
+
+// The same test with its rejections decided before any division.  The four determinants are
+// built from shared 2x2 minors in the reference's association, so detA, X, Y, Z are bit-identical
+// to det3(); a miss is declared early only when the quotient the reference would form is beyond
+// its threshold by more than the rounding of one division (factor 1 +- 2^-40), otherwise the exact
+// sequence above runs.  `tcut` <= maxT: a hit farther than tcut may be reported as maxT (it
+// cannot replace the current nearest hit, and for shadow queries tcut == maxT).
+DEV double tri_test_fast(const TriOps &tr, d3 o, d3 d, double minT, double maxT, double tcut)
+{
+    const d3 v0 = tr.v0, ab = tr.ab, ac = tr.ac;
+    const double m3 = ab.y * ac.z - ac.y * ab.z;
+    const d3 ae = sub3(v0, o);
+    const double m1 = ac.y * d.z - d.y * ac.z;
+    const double m2 = d.y * ab.z - ab.y * d.z;
+    const double detA = ab.x * m1 + ac.x * m2 + d.x * m3;
+    const double m4 = d.y * ae.z - ae.y * d.z;
+    const double m5 = ae.y * ac.z - ac.y * ae.z;
+    const double m6 = ab.y * ae.z - ae.y * ab.z;
+    const double X = ae.x * m1 + ac.x * m4 + d.x * m5;          // det3(ae, ac, d)
+    const double Y = ab.x * (-m4) + ae.x * m2 + d.x * m6;       // det3(ab, ae, d)
+    const double Z = ab.x * (-m5) + ac.x * (-m6) + ae.x * m3;   // det3(ab, ac, ae)
+    const double ad = fabs(detA);
+    if (ad > 1e-150 && ad < 1e150) {
+        const double sg = detA < 0 ? -1.0 : 1.0;
+        const double sX = sg * X, sY = sg * Y, sZ = sg * Z;
+        const double up = ad * (1.0 + 0x1p-40);
+        bool miss = (sX < -1e-150) || (sX > up) || (sY < -1e-150) || (sX + sY > ad * (1.0 + 0x1p-30)) ||
+                    (sZ < (minT * ad) * (1.0 - 0x1p-40)) || (sZ > (tcut * ad) * (1.0 + 0x1p-40));
+        if (miss && fabs(X) < 1e150 && fabs(Y) < 1e150 && fabs(Z) < 1e150) return maxT;
+    }
+    double alpha = X / detA;
+    if (alpha < 0 || alpha > 1) return maxT;
+    double beta = Y / detA;
+    if (beta < 0 || beta > 1 - alpha) return maxT;
+    double t = Z / detA;
+    if (t < minT || t > maxT) return maxT;
+    return t;
+}
+
+// Sphere::intersect (Sphere.h:35-77) without the hit-record update; returns t or maxT.
+DEV double sph_test(const rt_sph_rec *sp, d3 o, d3 d, double d2, double minT, double maxT)
+{
+    d3 emc = sub3(o, ld3(sp->center));
+    double r = sp->radius;
+    double ddotemc = dot3(d, emc);
+    double disc = (ddotemc * ddotemc) - d2 * (dot3(emc, emc) - r * r);
+    if (disc < 0) return maxT;
+    double sq = sqrt(disc);
+    double root1 = (-ddotemc + sq) / d2;
+    double root2 = (-ddotemc - sq) / d2;
+    double t = root1;
+    if (root1 < 0 || (root2 > minT && root2 < root1)) t = root2;
+    if (t < minT || t > maxT) return maxT;
+    return t;
+}
+

@@ -1,0 +1,100 @@
+// Sharded ray/hit queues (wave-aggregated pushes, chunked reads) and the run-reduced accumulation of
+// pixel contributions.
+#pragma once
+#include "device_math.hpp"
+#include "device_records.hpp"
+
+DEV int global_row(const FrameParams &P, int local_row)
+{
+    int band = local_row / P.band_rows;
+    int within = local_row - band * P.band_rows;
+    return (band * P.n_parts + P.part) * P.band_rows + within;
+}
+
+// Wave-aggregated queue push into this block's shard: one atomic per wave, lanes take
+// consecutive slots.  Returns the record index in the whole queue.
+DEV uint32_t wave_reserve(bool want, uint32_t *shard_counters, uint32_t shard_cap, uint32_t *overflow, bool *ok)
+{
+    const uint32_t shard = blockIdx.x & (N_SHARDS - 1);
+    unsigned long long mask = __ballot(want);
+    uint32_t n = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    if (n) {
+        int leader = __ffsll((long long)mask) - 1;
+        int lane = (int)(threadIdx.x & 63);
+        if (lane == leader) base = atomicAdd(&shard_counters[shard], n);
+        base = (uint32_t)__shfl((int)base, leader);
+    }
+    uint32_t rank = (uint32_t)__popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
+    uint32_t slot = base + rank;
+    *ok = want && slot < shard_cap;
+    if (want && slot >= shard_cap) *overflow = 1u;
+    return shard * shard_cap + slot;
+}
+
+// View of a sharded queue as one list of 64-item chunks.  Lane l keeps shard l's item count and
+// the index of its first chunk; chunk c belongs to the last shard whose first chunk is <= c.
+struct ShardMap {
+    uint32_t items;      // this lane's shard: number of items
+    uint32_t first;      // this lane's shard: first chunk index
+    uint32_t total;      // chunks in all shards
+};
+DEV ShardMap shard_map(const uint32_t *shard_counters, uint32_t shard_cap, uint32_t items_per_record)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    ShardMap m;
+    uint32_t n = shard_counters[lane];
+    if (n > shard_cap) n = shard_cap;
+    m.items = n * items_per_record;
+    uint32_t chunks = (m.items + 63u) >> 6;
+    uint32_t incl = chunks;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += v;
+    }
+    m.first = incl - chunks;
+    m.total = (uint32_t)__shfl((int)incl, 63);
+    return m;
+}
+// For chunk c (same in all lanes): shard, and this lane's item index inside the shard (or -1).
+DEV int shard_locate(const ShardMap &m, uint32_t c, int *shard_out, int pos_in_chunk = -1)
+{
+    const unsigned long long le = __ballot(m.first <= c && m.items > 0);
+    const int shard = 63 - __clzll((long long)le);
+    const uint32_t first = (uint32_t)__shfl((int)m.first, shard);
+    const uint32_t items = (uint32_t)__shfl((int)m.items, shard);
+    const uint32_t idx = (c - first) * 64u + (uint32_t)(pos_in_chunk >= 0 ? pos_in_chunk : (int)(threadIdx.x & 63));
+    *shard_out = shard;
+    return idx < items ? (int)idx : -1;
+}
+
+// Adds w*c to a pixel.  Lanes that hold the same pixel in a contiguous run of lanes are summed
+// first and the run's first lane issues the (memory-side) FP64 atomics.  `in_queue` lanes take
+// part in runs even when they contribute nothing (`valid` false), so a shadowed light does not
+// split the run of its hit.
+DEV void accum_add_runs(double *accum, bool in_queue, bool valid, uint32_t pixel, double w, d3 c)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t key = in_queue ? pixel : 0xFFFFFFFFu;
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    const bool head = (lane == 0) || prev != key;
+    // run id = number of run heads at or before this lane: equal ids <=> same contiguous run
+    const unsigned long long heads = __ballot(head);
+    const int run = __popcll(heads & ((2ull << lane) - 1ull));
+    double vx = valid ? w * c.x : 0.0, vy = valid ? w * c.y : 0.0, vz = valid ? w * c.z : 0.0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int orun = __shfl_down(run, off);
+        const bool same = lane + off < 64 && orun == run;
+        if (__ballot(same) == 0) break;      // runs are contiguous: no partner at this distance, none farther
+        const double ox = __shfl_down(vx, off), oy = __shfl_down(vy, off), oz = __shfl_down(vz, off);
+        if (same) { vx += ox; vy += oy; vz += oz; }
+    }
+    if (in_queue && head && (vx != 0.0 || vy != 0.0 || vz != 0.0)) {
+        unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 0], vx);
+        unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 1], vy);
+        unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 2], vz);
+    }
+}
+

@@ -1,0 +1,493 @@
+// The kernels of the wavefront pipeline (one generation of the ray tree per launch):
+//   k_closest<PRIMARY>  ray generation (Camera.h:112-230) fused with the closest-hit query, the hit
+//                       record (Solid.h:110-125) and secondary-ray spawning (Camera.h:232-314)
+//   k_closest<queued>   the same for generations 1..5, rays read from the queue
+//   k_shadow            one item per (hit, light): shadow query (Octree.h:1198-1264), Phong terms
+//                       (Camera.h:365-488), FP64 accumulation into the frame
+//   k_lightcam          deferred light-camera density queries (Camera.h:406-451)
+//   k_photons           a light camera's photon pass (LightCam.h:207-556)
+//   k_collect_counts, k_finalize (/spp, clamp, *255, (int); Camera.h:217-227, Driver.cpp:722,758-760)
+//   k_debug_intersect   one primitive test per thread (rt_debug_intersect)
+#pragma once
+#include "hierarchy_walk.hpp"
+#include "lightcam_query.hpp"
+#include "octree_walk.hpp"
+#include "queues.hpp"
+#include "shading.hpp"
+
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 1
+#endif
+template <bool PRIMARY, bool BVH>
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, QueueSet Q)
+{
+    // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
+    int *stack = &s_lds[BVH ? threadIdx.x : 0];
+    fill_node_cache(P.S, BVH);
+    const int lane = (int)(threadIdx.x & 63);
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    ShardMap smap;
+    smap.items = smap.first = smap.total = 0;
+    if (!PRIMARY) smap = shard_map(&Q.counts[CNT_RAYS(Q.generation)], Q.in_shard_cap, 1u);
+    const long long n_chunks = PRIMARY ? (Q.chunk_end - Q.chunk_begin) : (long long)smap.total;
+    const bool cull = P.cull_closest != 0;
+    WalkCount wc{};
+
+    for (long long chunk = wave; chunk < n_chunks; chunk += n_waves) {
+        bool active;
+        d3 o, d;
+        double A = 1.0, coef = 1.0;
+        uint32_t pixel = 0, meta = 5u | 0x100u;
+        bool first_sample = false;
+        if (PRIMARY) {
+            // Primary ordering: pixels in 8x8 blocks (row-major inside a block), the N*N samples of a
+            // pixel in consecutive positions; a wave takes 64 consecutive positions.
+            const int N = P.N;
+            const long long pos = (Q.chunk_begin + chunk) * 64 + lane;
+            const int spp = N * N;
+            const long long pseq = pos / spp;
+            const int smp = (int)(pos - pseq * spp);
+            const long long blk = pseq >> 6;
+            const int within = (int)(pseq & 63);
+            const int by = (int)(blk / P.blocks_x), bx = (int)(blk - (long long)by * P.blocks_x);
+            const int j = bx * 8 + (within & 7), lrow = by * 8 + (within >> 3);
+            const int si = smp / N, sj = smp - si * N;
+            active = j < P.cam.resx && lrow < P.local_rows;
+            const int i = global_row(P, lrow);
+            pixel = (uint32_t)lrow * (uint32_t)P.cam.resx + (uint32_t)j;
+            first_sample = (si == 0 && sj == 0);
+            const rt_camera &c = P.cam;
+            const uint32_t gpix = (uint32_t)i * (uint32_t)c.resx + (uint32_t)j;
+            const uint32_t sample = (uint32_t)(si * N + sj);
+            double p, q, r;
+            if (N > 1) {
+                double spw = c.pix_width / N;
+                double randX = normed_rand(gpix, sample, 0, P.seed);
+                double randY = normed_rand(gpix, sample, 1, P.seed);
+                randX -= .5;
+                randY -= .5;
+                double edgeX = (j - .5) * c.pix_width;
+                double edgeY = (i - .5) * c.pix_width;
+                double j_m = edgeX + sj * spw + .5 * spw;
+                double i_m = edgeY + si * spw + .5 * spw;
+                randX *= spw;
+                randY *= spw;
+                j_m += randX;
+                i_m += randY;
+                p = c.l + j_m;
+                q = c.t - i_m;
+            } else {
+                p = c.l + j * c.pix_width;
+                q = c.t - i * c.pix_width;
+            }
+            r = -c.d;
+            d3 u = ld3(c.u), v = ld3(c.v), w = ld3(c.w), e = ld3(c.e);
+            d = unit3(add3(add3(scale3(p, u), scale3(q, v)), scale3(r, w)));
+            o = e;
+            if (P.aperture > 0) {
+                d3 uOff = scale3(P.aperture, scale3(normed_rand(gpix, sample, 2, P.seed) - .5, u));
+                d3 vOff = scale3(P.aperture, scale3(normed_rand(gpix, sample, 3, P.seed) - .5, v));
+                o = add3(o, add3(uOff, vOff));
+                p = c.l + j * c.pix_width;
+                q = c.t - i * c.pix_width;
+                d3 focus = add3(add3(add3(scale3(p, u), scale3(q, v)), scale3(r, w)), e);
+                d = unit3(sub3(focus, o));
+            }
+        } else {
+            int shard;
+            const int local = shard_locate(smap, (uint32_t)chunk, &shard);
+            active = local >= 0;
+            const RayRec *rr = &Q.rays_in[active ? (size_t)shard * Q.in_shard_cap + (uint32_t)local : 0];
+            o = ld3(rr->o);
+            d = ld3(rr->d);
+            A = rr->A;
+            coef = rr->coef;
+            pixel = rr->pixel;
+            meta = rr->meta;
+        }
+
+        double best_t = 0;
+        int best = -1, best_prim = -1;
+        if (active) {
+            if (BVH) {
+                const double d2 = dot3(d, d);
+                Best bst;
+                bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1; bst.prim = -1;
+                if (root_gate(P.S, o, d, d2, 10000000000.0)) {
+                    const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
+                    WC_ADD(wc, rays);
+                    bvh_closest<true>(P.S, o, d, d2, rb, bst, stack, wc);
+                    bvh_closest<false>(P.S, o, d, d2, rb, bst, stack, wc);
+                }
+                best_t = bst.t;
+                best = bst.slot;
+                best_prim = bst.prim;
+            } else {
+                trace_closest(P.S, o, d, cull, .01, best_t, best);
+            }
+        }
+        const rt_tri_rec *tri_arr = BVH ? P.S.btri : P.S.tri;
+        const rt_sph_rec *sph_arr = BVH ? P.S.bsph : P.S.sph;
+        const uint32_t *sph_prim_arr = BVH ? P.S.bsph_prim : P.S.sph_prim;
+
+        const bool first = (meta & 0x100u) != 0;
+        const int L = (int)(meta & 0xffu);
+        const double wloc = first ? A : A * coef;
+        bool hit = active && best >= 0;
+        accum_add_runs(P.accum, active, active && !hit, pixel, wloc, ld3(P.S.bg));
+
+        // hit record (Solid.h:110-125)
+        d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0), refl = mk3(0, 0, 0);
+        int prim = -1, mat = 0;
+        rt_material m;
+        m.Ks = 0; m.T = 0; m.ior = 1;
+        if (hit) {
+            hit_geometry(P.S, tri_arr, sph_arr, sph_prim_arr, P.flags, o, d, .01, best_t, best, best_prim, &prim, &n, &Pt);
+            refl = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));
+            mat = P.S.prim_material[prim];
+            m = load_material(P.S, mat, true);
+        }
+        if (PRIMARY && active && first_sample && P.hit_id) P.hit_id[pixel] = prim;
+
+        // Queue pushes.  The three reservations (hit record, refraction ray, reflection ray) are made
+        // with two atomics -- both kinds of ray go to the same queue -- issued back to back by one lane,
+        // so a wave waits for one round trip to the counters instead of three in a row.
+        const bool want_hit = hit && P.S.n_lights > 0;
+        const bool spawn = hit && L > 0 && !(coef < .01);       // Camera.h:244-307
+        const double coef2 = coef * m.Ks;
+        const bool want_refr = spawn && m.T > 0;
+        const bool want_refl = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
+        const unsigned long long mask_h = __ballot(want_hit), mask_a = __ballot(want_refr), mask_b = __ballot(want_refl);
+        const uint32_t n_h = (uint32_t)__popcll(mask_h), n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b);
+        const uint32_t shard = blockIdx.x & (N_SHARDS - 1);
+        uint32_t base_h = 0, base_r = 0;
+        if (lane == 0) {
+            if (n_h) base_h = atomicAdd(&Q.counts[CNT_HITS(Q.generation) + shard], n_h);
+            if (n_a + n_b) base_r = atomicAdd(&Q.counts[CNT_RAYS(Q.generation + 1) + shard], n_a + n_b);
+        }
+        base_h = (uint32_t)__shfl((int)base_h, 0);
+        base_r = (uint32_t)__shfl((int)base_r, 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t slot_h = base_h + (uint32_t)__popcll(mask_h & below);
+        const uint32_t slot_a = base_r + (uint32_t)__popcll(mask_a & below);
+        const uint32_t slot_b = base_r + n_a + (uint32_t)__popcll(mask_b & below);
+        if ((want_hit && slot_h >= Q.hit_shard_cap) || (want_refr && slot_a >= Q.out_shard_cap) ||
+            (want_refl && slot_b >= Q.out_shard_cap))
+            Q.counts[CNT_OVERFLOW] = 1u;
+
+        if (want_hit && slot_h < Q.hit_shard_cap) {
+            HitRec *h = &Q.hits[(size_t)shard * Q.hit_shard_cap + slot_h];
+            h->P[0] = Pt.x; h->P[1] = Pt.y; h->P[2] = Pt.z;
+            const d3 n2 = unit3(n);
+            const d3 vv = unit3(sub3(o, Pt));
+            const d3 n3 = unit3(n2);
+            h->n[0] = n2.x; h->n[1] = n2.y; h->n[2] = n2.z;
+            h->nn[0] = n3.x; h->nn[1] = n3.y; h->nn[2] = n3.z;
+            h->v[0] = vv.x; h->v[1] = vv.y; h->v[2] = vv.z;
+            h->weight = wloc;
+            h->pixel = pixel;
+            h->prim = prim;
+            h->mat = mat;
+        }
+        if (want_refr && slot_a < Q.out_shard_cap) {
+            const d3 rd = refract_dir(d, n, m.ior, false);
+            RayRec *r = &Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_a];
+            r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
+            r->d[0] = rd.x; r->d[1] = rd.y; r->d[2] = rd.z;
+            r->A = A * m.T;
+            r->coef = m.T * coef;
+            r->pixel = pixel;
+            r->meta = (uint32_t)(L - 1) | 0x100u;
+        }
+        if (want_refl && slot_b < Q.out_shard_cap) {
+            RayRec *r = &Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_b];
+            r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
+            r->d[0] = refl.x; r->d[1] = refl.y; r->d[2] = refl.z;
+            r->A = A;
+            r->coef = coef2;
+            r->pixel = pixel;
+            r->meta = (uint32_t)(L - 1);
+        }
+    }
+#ifdef RT_COUNT
+    walk_count_flush(wc, PRIMARY ? 0 : 8);
+#endif
+}
+
+
+#ifndef RT_MIN_WAVES_SHADOW
+#define RT_MIN_WAVES_SHADOW 4
+#endif
+template <bool BVH>
+__global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams P, QueueSet Q)
+{
+    // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
+    int *stack = &s_lds[BVH ? threadIdx.x : 0];
+    fill_node_cache(P.S, BVH);
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const uint32_t nl = (uint32_t)P.S.n_lights;
+    // work items are (hit, light) pairs, the lights of one hit in consecutive items
+    const ShardMap smap = shard_map(&Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, nl);
+    const bool cull = P.cull_shadow != 0;
+    WalkCount wc{};
+    for (long long chunk = wave; chunk < (long long)smap.total; chunk += n_waves) {
+        int shard;
+        const int item = shard_locate(smap, (uint32_t)chunk, &shard);
+        const bool active = item >= 0;
+        const uint32_t h = active ? (uint32_t)item / nl : 0u;
+        const int li = active ? (int)((uint32_t)item - h * nl) : 0;
+        const HitRec *hr = &Q.hits[(size_t)shard * Q.hit_shard_cap + h];
+        const d3 Pt = ld3(hr->P);
+        const d3 lpos = ld3(load_light(P.S, li, true).pos);
+        const uint32_t pixel = hr->pixel;
+        bool lit = false;
+        int defer_cam = -1;
+        d3 local = mk3(0, 0, 0);
+        if (active) {
+            const d3 toL = sub3(lpos, Pt);
+            const d3 rd = unit3(toL);
+            const double maxT = norm3(toL) - .01;
+            bool only = false;
+            int closest = -1;
+            bool occluded;
+            if (BVH) {
+                // no transparent sphere in the scene: "occluded" is "any hit", and never "only transparent"
+                const double d2 = dot3(rd, rd);
+                occluded = false;
+#ifdef RT_EXP_SHADOW_SKIP          /* experiment: cost of the kernel without the traversal */
+                if (false) {
+#else
+                if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
+#endif
+                    const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
+                    WC_ADD(wc, rays);
+                    occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack, wc) ||
+                               bvh_any<false>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack, wc);
+                }
+            } else {
+                occluded = trace_shadow(P.S, Pt, rd, hr->prim, maxT, cull, &only, &closest);
+            }
+            if (occluded && only) {
+                // shadowed by transparent spheres only: the light camera of (that sphere, this light)
+                // decides how much light arrives (Camera.h:406-451); evaluated in k_lightcam
+                if (P.lc_mask) P.lc_mask[pixel] = 1;
+                if (P.S.lc_table && closest >= 0) {
+                    const int rank = P.S.prim_lc_rank[closest];
+                    if (rank >= 0) defer_cam = rank * P.S.n_lights + li;
+                }
+            }
+            lit = !occluded;
+            if (lit) {
+                const rt_light lgt = load_light(P.S, li, true);     // read again here rather than kept in registers through the walk
+                local = phong_terms(load_material(P.S, hr->mat, true), hr, &lgt, rd, .999999);
+            }
+        }
+        if (!BVH && P.S.lc_table) {
+            bool ok;
+            const bool want = defer_cam >= 0;
+            const uint32_t slot = wave_reserve(want, &Q.counts[CNT_DEFER(Q.generation)], Q.hit_shard_cap, &Q.counts[CNT_OVERFLOW + 1], &ok);
+            if (ok) {
+                HitRec *dr = &Q.deferred[slot];
+                *dr = *hr;
+                dr->light = li;
+                dr->cam = defer_cam;
+            } else if (want) {   // queue full: evaluate here
+                const double kfac = lc_calc_intensity(P.S.lc_table, defer_cam, Pt);
+                if (kfac > .01) {
+                    lit = true;
+                    const rt_light lgt = load_light(P.S, li, true);
+                    local = phong_terms(load_material(P.S, hr->mat, true), hr, &lgt, unit3(sub3(lpos, Pt)), kfac);
+                }
+            }
+        }
+        accum_add_runs(P.accum, active, lit, pixel, hr->weight, local);
+    }
+#ifdef RT_COUNT
+    walk_count_flush(wc, 16);
+#endif
+}
+
+// Deferred light-camera evaluations of one generation: density query, then the same shading as a
+// lit point with the query result as the factor (Camera.h:444-476).
+// LC_PER_WAVE < 64 spreads a generation's queries over more waves (measured: no gain, the time of a
+// pass is the chain of dependent fetches of its single longest query).
+#ifndef LC_PER_WAVE
+#define LC_PER_WAVE 64
+#endif
+__global__ __launch_bounds__(256) void k_lightcam(FrameParams P, QueueSet Q)
+{
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const int lane = (int)(threadIdx.x & 63);
+    const int parts = 64 / LC_PER_WAVE;
+    const ShardMap smap = shard_map(&Q.counts[CNT_DEFER(Q.generation)], Q.hit_shard_cap, 1u);
+    for (long long vc = wave; vc < (long long)smap.total * parts; vc += n_waves) {
+        const long long chunk = vc / parts;
+        const int part = (int)(vc - chunk * parts);
+        int shard;
+        const int item = shard_locate(smap, (uint32_t)chunk, &shard, part * LC_PER_WAVE + (lane % LC_PER_WAVE));
+        const bool active = item >= 0 && lane < LC_PER_WAVE;
+        const HitRec *hr = &Q.deferred[(size_t)shard * Q.hit_shard_cap + (active ? (uint32_t)item : 0u)];
+        bool lit = false;
+        d3 local = mk3(0, 0, 0);
+        const d3 Pt = ld3(hr->P);
+        const double kfac = lc_calc_intensity_wave(P.S.lc_table, active ? hr->cam : 0, Pt, active);
+        if (active) {
+            const rt_light *lt = &P.S.lights[hr->light];
+            if (kfac > .01) {
+                lit = true;
+                local = phong_terms(load_material(P.S, hr->mat, false), hr, lt, unit3(sub3(ld3(lt->pos), Pt)), kfac);
+            }
+        }
+        accum_add_runs(P.accum, active, lit, hr->pixel, hr->weight, local);
+    }
+}
+
+// Light rays of one light camera (LightCam::lightCast, recursiveCastLightRays, castLightRay:
+// LightCam.h:207-306, 340-556).  One lane per sub-pixel (si, sj) of the N x N grid; each lane follows
+// its refraction / total-internal-reflection chain and writes every impact into its own row of
+// `slots` (21 entries: the first hit plus a depth budget of 20), so the host can read them back in
+// the reference's order.
+struct PhotonParams {
+    DevScene S;
+    double u[3], v[3], w[3], e[3];
+    double d, l, t, pix_width;
+    int32_t N;
+    uint32_t flags;
+    int32_t cull;
+    lightcam::Point *slots;     // N*N rows of 21
+    int32_t *counts;            // N*N
+};
+#define LC_MAX_IMPACTS 21
+
+__global__ __launch_bounds__(256) void k_photons(PhotonParams Q)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)Q.N * Q.N;
+    if (idx >= total) return;
+    const int si = (int)(idx / Q.N), sj = (int)(idx - (long long)si * Q.N);
+    const double spw = Q.pix_width / Q.N;
+    double p, q;
+    if (Q.N > 1) {
+        const double edgeX = (0 - .5) * Q.pix_width;
+        const double edgeY = (0 - .5) * Q.pix_width;
+        const double j_m = edgeX + sj * spw + .5 * spw;
+        const double i_m = edgeY + si * spw + .5 * spw;
+        p = Q.l + j_m;
+        q = Q.t - i_m;
+    } else {
+        p = Q.l + 0 * Q.pix_width;
+        q = Q.t - 0 * Q.pix_width;
+    }
+    const double r = -Q.d;
+    d3 d = unit3(add3(add3(scale3(p, ld3(Q.u)), scale3(q, ld3(Q.v))), scale3(r, ld3(Q.w))));
+    d3 o = ld3(Q.e);
+    double coef = 1.0, CoR = 1.0;
+    int budget = 20, n_out = 0, calls = 0;
+    bool top = true;
+    lightcam::Point *row = Q.slots + idx * LC_MAX_IMPACTS;
+    while (n_out < LC_MAX_IMPACTS) {
+        ++calls;                                                   // one castLightRay call
+        if (!(coef > .05)) break;                                  // LightCam.h:502
+        double t;
+        int best;
+        trace_closest(Q.S, o, d, Q.cull != 0, .000001, t, best);    // selfIntersectBias 1e-6, LightCam.h:44
+        if (best < 0) break;
+        int prim;
+        d3 n, Pt;
+        hit_geometry(Q.S, Q.S.tri, Q.S.sph, Q.S.sph_prim, Q.flags, o, d, .000001, t, best, -1, &prim, &n, &Pt);
+        const rt_material m = Q.S.materials[Q.S.prim_material[prim]];
+        lightcam::Point pt;
+        pt.x = Pt.x; pt.y = Pt.y; pt.z = Pt.z;
+        pt.w = coef * (1.0 - m.T);                                 // LightCam.h:536
+        row[n_out++] = pt;
+        if (top && !(best & SLOT_SPHERE)) break;                    // LightCam.h:360
+        if (budget <= 0) break;
+        CoR *= m.Ks;                                               // LightCam.h:380
+        if (coef < .01) break;
+        if (CoR < .01 && m.T == 0) break;
+        if (!(m.T > 0)) break;                                     // only refraction continues the chain
+        d = refract_dir(d, n, m.ior, true);
+        o = Pt;
+        coef = coef * m.T;
+        budget -= 1;
+        top = false;
+    }
+    Q.counts[idx] = n_out | (calls << 8);
+}
+
+// totals[0]=closest rays, [1]=shadow rays, [2..7]=rays per generation (generation 0 is filled in by the
+// host, which knows the number of primary samples), [8..13]=hits per generation, [15]=overflow
+__global__ void k_collect_counts(const uint32_t *counts, unsigned long long *totals, int n_lights)
+{
+    const int lane = (int)threadIdx.x;   // one wave, lane = shard
+    if (blockIdx.x != 0 || lane >= N_SHARDS) return;
+    for (int g = 0; g < 6; ++g) {
+        unsigned long long r = (g == 0) ? 0ull : counts[CNT_RAYS(g) + lane];
+        unsigned long long h = counts[CNT_HITS(g) + lane];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            r += __shfl_down(r, off);
+            h += __shfl_down(h, off);
+        }
+        if (lane == 0) {
+            totals[2 + g] += r;
+            totals[8 + g] += h;
+            totals[0] += r;
+            totals[1] += h * (unsigned long long)n_lights;
+        }
+    }
+    if (lane == 0) totals[15] += counts[CNT_OVERFLOW];
+}
+
+__global__ __launch_bounds__(256) void k_finalize(const double *accum, long long n_values, int spp, double *out_f64,
+                                                  uint8_t *out_u8)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride) {
+        double c = accum[i] / (double)spp;
+        c = (c < 1.0) ? c : 1.0;        // std::min(1.0, c)
+        c = (0.0 < c) ? c : 0.0;        // std::max(0.0, c)
+        double v = c * 255;
+        if (out_f64) out_f64[i] = v;
+        if (out_u8) out_u8[i] = (uint8_t)(int)v;
+    }
+}
+
+// One primitive test per thread with the device functions the kernels use (rt_debug_intersect).
+__global__ void k_debug_intersect(int kind, int n, const double *geom, const double *rays, double minT, double maxT, double *out)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const d3 o = ld3(rays + (size_t)i * 6), d = ld3(rays + (size_t)i * 6 + 3);
+    double t = maxT;
+    d3 nrm = mk3(0, 0, 0);
+    if (kind == 0 || kind == 1) {
+        const double *g = geom + (size_t)i * 9;
+        rt_tri_rec tr;
+        for (int k = 0; k < 3; ++k) { tr.v0[k] = g[k]; tr.ab[k] = g[k] - g[3 + k]; tr.ac[k] = g[k] - g[6 + k]; }   // Triangle.h:40-46
+        tr.prim = 0; tr._pad0 = 0; tr._pad1[0] = tr._pad1[1] = 0;
+        if (kind == 0) { double al, be; t = tri_test(&tr, o, d, minT, maxT, &al, &be); }
+        else {
+            TriOps ops;
+            ops.v0 = ld3(tr.v0); ops.ab = ld3(tr.ab); ops.ac = ld3(tr.ac); ops.prim = 0; ops.key = 0;
+            t = tri_test_fast(ops, o, d, minT, maxT, maxT);
+        }
+    } else if (kind == 2) {
+        const double *g = geom + (size_t)i * 4;
+        rt_sph_rec sp;
+        sp.center[0] = g[0]; sp.center[1] = g[1]; sp.center[2] = g[2]; sp.radius = g[3];
+        t = sph_test(&sp, o, d, dot3(d, d), minT, maxT);
+        if (t < maxT) nrm = unit3(div3(sub3(add3(o, scale3(t, d)), ld3(sp.center)), sp.radius));
+    } else {
+        const double *g = geom + (size_t)i * 4;
+        rt_node nd;
+        nd.center[0] = g[0]; nd.center[1] = g[1]; nd.center[2] = g[2]; nd.radius = g[3];
+        double entry;
+        t = bound_test(&nd, o, d, dot3(d, d), minT, maxT, &entry);
+    }
+    out[(size_t)i * 4] = t; out[(size_t)i * 4 + 1] = nrm.x; out[(size_t)i * 4 + 2] = nrm.y; out[(size_t)i * 4 + 3] = nrm.z;
+}
+

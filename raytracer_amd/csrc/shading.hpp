@@ -1,0 +1,95 @@
+// What happens at a hit: the hit record's geometry (Solid.h:110-125), refraction (Camera.h:260-302),
+// the Phong terms of one light (Solid.h:128-172), and the counter-based stand-in for rand().
+#pragma once
+#include "primitives.hpp"
+
+// Geometry of a found hit (Solid.h:110-125): primitive id, unit normal, impact point.
+// `best` is a slot of the given record arrays (| SLOT_SPHERE for spheres).
+DEV void hit_geometry(const DevScene &S, const rt_tri_rec *tri_arr, const rt_sph_rec *sph_arr, const uint32_t *sph_prim_arr,
+                      uint32_t flags, d3 o, d3 d, double minT, double t, int best, int known_prim, int *prim_out, d3 *n_out,
+                      d3 *P_out)
+{
+    d3 nraw;
+    int prim = known_prim;       // >= 0: the walk already knows it, no need to go through the record
+    if (best & SLOT_SPHERE) {
+        const int s = best & ~SLOT_SPHERE;
+        if (known_prim < 0) prim = (int)(sph_prim_arr[s] & ~RT_SPH_TRANSPARENT);
+        const rt_sph_rec *sp = &sph_arr[s];
+        nraw = div3(sub3(add3(o, scale3(t, d)), ld3(sp->center)), sp->radius);
+    } else {
+        const rt_tri_rec *tr = &tri_arr[best];
+        if (known_prim < 0) prim = tr->prim;
+        const double *pn = &S.prim_normals[(size_t)prim * 12];
+        nraw = ld3(pn);
+        if ((flags & RT_FLAG_PHONG_NORMALS) && (S.prim_flags[prim] & RT_PRIM_HAS_VNORMALS)) {
+            double al, be;
+            (void)tri_test(tr, o, d, minT, 10000000000.0, &al, &be);
+            d3 n0 = ld3(pn + 3), n1 = ld3(pn + 6), n2 = ld3(pn + 9);
+            nraw = add3(add3(scale3(al, n1), scale3(be, n2)), scale3(1 - (al + be), n0));
+        }
+    }
+    *prim_out = prim;
+    *n_out = unit3(nraw);
+    *P_out = mk3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
+}
+
+// Refraction / total-internal-reflection direction at a transparent hit (Camera.h:260-302,
+// LightCam.h:397-472).  `renormalize` is the light camera's variant (LightCam.h:440).
+DEV d3 refract_dir(d3 d, d3 n, double ior, bool renormalize)
+{
+    d3 nn = n;
+    d3 V = neg3(d);
+    double dt = dot3(nn, V);
+    if (dt >= 0) ior = 1.0 / ior;
+    else { nn = neg3(nn); dt = -dt; }
+    double disc = 1 - (1 - (dt * dt)) * (ior * ior);
+    if (disc > 0) {
+        double sq = sqrt(disc);
+        d3 rd = mk3((nn.x * dt - V.x) * ior - nn.x * sq, (nn.y * dt - V.y) * ior - nn.y * sq,
+                    (nn.z * dt - V.z) * ior - nn.z * sq);
+        return renormalize ? unit3(rd) : rd;
+    }
+    return unit3(add3(d, scale3(2.0 * -dot3(d, nn), nn)));
+}
+
+// Diffuse + specular terms of one light at one hit (Solid.h:128-172), scaled by `kfac`
+// (Camera.h:465-476).  `rd` is the unit vector from the hit point to the light.
+DEV d3 phong_terms(const rt_material &m, const HitRec *hr, const rt_light *lt, d3 rd, double kfac)
+{
+    const d3 normal = ld3(hr->n);
+    d3 local = mk3(0, 0, 0);
+    if (m.Ks > 0) {
+        d3 nn = ld3(hr->nn);
+        d3 v = ld3(hr->v);
+        d3 rdir = unit3(add3(neg3(rd), scale3(2.0 * dot3(rd, nn), nn)));
+        double a = dot3(rdir, v);
+        double pw = pow((a < 0.0) ? 0.0 : a, m.Shine);
+        double ik = lt->intensity * m.Ks;
+        d3 comp = mk3((ik * lt->color[0]) * pw, (ik * lt->color[1]) * pw, (ik * lt->color[2]) * pw);
+        local = add3(local, scale3(kfac, comp));
+    }
+    {
+        double a = dot3(rd, normal);
+        double dm = (a < 0.0) ? 0.0 : a;
+        double ik = lt->intensity * m.Kd;
+        d3 comp = mk3((ik * m.r) * dm, (ik * m.g) * dm, (ik * m.b) * dm);
+        local = add3(local, scale3(kfac, comp));
+    }
+    return local;
+}
+
+// Counter-based stand-in for the reference's shared rand() % 1000 / 1000 (Camera.h:99-103).
+DEV uint32_t hash_rng(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
+{
+    uint32_t h = seed * 0x9E3779B1u + 0x85EBCA6Bu;
+    h ^= pixel + 0x9E3779B9u + (h << 6) + (h >> 2);
+    h ^= sample + 0x9E3779B9u + (h << 6) + (h >> 2);
+    h ^= dim + 0x9E3779B9u + (h << 6) + (h >> 2);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+DEV double normed_rand(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
+{
+    return (double)(hash_rng(pixel, sample, dim, seed) % 1000u) / 1000.0;
+}
+
