@@ -178,17 +178,29 @@ def main():
     band = BAND_ROWS if world > 1 else 0
     dev = torch.device("cuda", dev_index)
     staged = world > 1 and args.backend == "gloo"
-    fg = FrameGather(resx, resy, band, world, rank, torch.device("cpu") if staged else dev, dist)
-    assert fg.local_rows == rt.part_rows(cam, band, world, rank)
-    render_buf = torch.zeros_like(fg.local, device=dev) if staged else fg.local
+    # Two frame buffers in turn: the gather of one frame (RCCL, on torch's stream) may still be reading its
+    # buffer while the next frame is rendered (on the context's stream) into the other one.
+    n_buf = 2 if world > 1 else 1
+    fgs = [FrameGather(resx, resy, band, world, rank, torch.device("cpu") if staged else dev, dist) for _ in range(n_buf)]
+    assert fgs[0].local_rows == rt.part_rows(cam, band, world, rank)
+    render_bufs = [torch.zeros_like(fg.local, device=dev) if staged else fg.local for fg in fgs]
+    gathered = [None] * n_buf          # event after the last gather that read buffer k
+    frame_no = [0]
 
     def step(flags):
-        st = gpu.render_device(cam, rgb_u8_ptr=render_buf.data_ptr(), num_samples=N, flags=flags, band_rows=band,
+        k = frame_no[0] % n_buf
+        frame_no[0] += 1
+        if gathered[k] is not None:
+            gathered[k].synchronize()
+        st = gpu.render_device(cam, rgb_u8_ptr=render_bufs[k].data_ptr(), num_samples=N, flags=flags, band_rows=band,
                                n_parts=world, part=rank)
         if world > 1:
             if staged:
-                fg.local.copy_(render_buf)
-            fg.gather()
+                fgs[k].local.copy_(render_bufs[k])
+            fgs[k].gather()
+            if not staged:
+                gathered[k] = torch.cuda.Event()
+                gathered[k].record()
         return st
 
     def fence():
