@@ -112,7 +112,7 @@ def measured_traffic(workload, kernel):
     with open(files[-1]) as f:
         js = json.load(f)
     n = rd = wr = 0.0
-    hit = req = 0.0
+    hit = req = valu = wait = cyc = 0.0
     for name, e in js.items():
         if not name.startswith(kernel) or "hbm_read_bytes_per_launch" not in e:
             continue
@@ -121,10 +121,16 @@ def measured_traffic(workload, kernel):
         wr += e["hbm_write_bytes_per_launch"] * e["dispatches"]
         hit += e["counters"].get("TCC_HIT_sum", 0.0)
         req += e["counters"].get("TCC_REQ_sum", 0.0)
+        valu += e["counters"].get("SQ_ACTIVE_INST_VALU", 0.0)
+        wait += e["counters"].get("SQ_WAIT_ANY", 0.0)
+        cyc += e["counters"].get("SQ_WAVE_CYCLES", 0.0)
     if n == 0:
         return None
     return {"bytes_per_launch": (rd + wr) / n, "read": rd / n, "write": wr / n, "launches": int(n),
-            "l2_hit_rate": hit / req if req else None, "source": os.path.relpath(files[-1], ROOT)}
+            "l2_hit_rate": hit / req if req else None,
+            "valu_issue_share_of_wave_cycles": valu / cyc if cyc else None,
+            "waiting_share_of_wave_cycles": wait / cyc if cyc else None,
+            "source": os.path.relpath(files[-1], ROOT)}
 
 
 def main():

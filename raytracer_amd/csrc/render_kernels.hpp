@@ -23,7 +23,6 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
 {
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
-    fill_node_cache(P.S, BVH);
     const int lane = (int)(threadIdx.x & 63);
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
@@ -31,6 +30,10 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
     smap.items = smap.first = smap.total = 0;
     if (!PRIMARY) smap = shard_map(&Q.counts[CNT_RAYS(Q.generation)], Q.in_shard_cap, 1u);
     const long long n_chunks = PRIMARY ? (Q.chunk_end - Q.chunk_begin) : (long long)smap.total;
+    // a block none of whose waves gets a chunk leaves before it copies anything into LDS (late
+    // generations of small frames fill only a few of the launched blocks)
+    if ((long long)blockIdx.x * (blockDim.x >> 6) >= n_chunks) return;
+    fill_node_cache(P.S, BVH);
     const bool cull = P.cull_closest != 0;
     WalkCount wc{};
 
@@ -224,12 +227,13 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
 {
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
-    fill_node_cache(P.S, BVH);
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     const uint32_t nl = (uint32_t)P.S.n_lights;
     // work items are (hit, light) pairs, the lights of one hit in consecutive items
     const ShardMap smap = shard_map(&Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, nl);
+    if ((long long)blockIdx.x * (blockDim.x >> 6) >= (long long)smap.total) return;   // no chunk for this block
+    fill_node_cache(P.S, BVH);
     const bool cull = P.cull_shadow != 0;
     WalkCount wc{};
     for (long long chunk = wave; chunk < (long long)smap.total; chunk += n_waves) {
