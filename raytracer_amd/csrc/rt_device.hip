@@ -543,15 +543,19 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     // The hierarchies answer "nearest / any hit over all primitives"; that equals the reference's
     // walk when every sphere is inside the root cube, and for shadow queries only when no
     // transparent sphere exists (checkOccluded3 is then order-free).
-    const bool bvh_closest_ok = may_cull && ctx->accel_usable;
-    const bool bvh_shadow_ok = bvh_closest_ok && !ctx->any_transparent_sphere;
+    bool bvh_closest_ok = may_cull && ctx->accel_usable;
     // at most three pending siblings per 4-wide level (BVH_STACK is the cap the builder checks against)
     int stack_entries = 3 * ctx->accel_depth + 1;
     if (stack_entries > BVH_STACK) stack_entries = BVH_STACK;
     if (stack_entries < 4) stack_entries = 4;
     // LDS per block: the stacks, the material and light tables, then as many top-of-tree nodes as fit
-    // beside them when four blocks share a compute unit (the register budget allows four waves per SIMD)
-    const size_t lds_stack = (size_t)stack_entries * 256 * sizeof(int);
+    // beside them when four blocks share a compute unit (the register budget allows four waves per SIMD).
+    // A block may ask for at most 64 KiB: a tree so deep that its stacks alone do not fit keeps to the
+    // octree walk.
+    size_t lds_stack = (size_t)stack_entries * 256 * sizeof(int);
+    if (lds_stack + 8192 > 64 * 1024) bvh_closest_ok = false;
+    if (!bvh_closest_ok) lds_stack = 0;
+    const bool bvh_shadow_ok = bvh_closest_ok && !ctx->any_transparent_sphere;
     P.S.mat_cached = ctx->n_materials < 64 ? ctx->n_materials : 64;
     P.S.light_cached = P.S.n_lights < 16 ? P.S.n_lights : 16;
     const size_t lds_tables = (size_t)(P.S.mat_cached + P.S.light_cached) * 64;
@@ -562,6 +566,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         if (const char *e = std::getenv("RT_NODE_CACHE")) room = std::atoll(e) < room ? std::atoll(e) : room;   // experiments
         // the triangle hierarchy first, the sphere hierarchy takes what is left; split evenly when both are large
         long long nt = P.S.n_tri_nodes, ns = P.S.n_sph_nodes;
+        if (!bvh_closest_ok) nt = ns = 0;
         if (nt + ns > room) {
             const long long half = room / 2;
             if (nt <= half) ns = room - nt;
