@@ -39,6 +39,8 @@ struct DevScene {
     const uint32_t *prim_flags;
     const int32_t *prim_material;
     const double *prim_normals;
+    const double *prim_units;             // per primitive 9 doubles: the flat normal normalised once, twice and three times more
+                                          // (Solid.h:119, Camera.h:382, Solid.h:153), constants of a flat triangle; zeros for spheres
     const rt_material *materials;
     const rt_light *lights;
     int32_t n_nodes, n_lights;

@@ -143,10 +143,11 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
         // hit record (Solid.h:110-125)
         d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0), refl = mk3(0, 0, 0);
         int prim = -1, mat = 0;
+        bool flat = false;
         rt_material m;
         m.Ks = 0; m.T = 0; m.ior = 1;
         if (hit) {
-            hit_geometry(P.S, tri_arr, sph_arr, sph_prim_arr, P.flags, o, d, .01, best_t, best, best_prim, &prim, &n, &Pt);
+            hit_geometry(P.S, tri_arr, sph_arr, sph_prim_arr, P.flags, o, d, .01, best_t, best, best_prim, &prim, &n, &Pt, &flat);
             refl = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));
             mat = P.S.prim_material[prim];
             m = load_material(P.S, mat, true);
@@ -182,9 +183,10 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
         if (want_hit && slot_h < Q.hit_shard_cap) {
             HitRec *h = &Q.hits[(size_t)shard * Q.hit_shard_cap + slot_h];
             h->P[0] = Pt.x; h->P[1] = Pt.y; h->P[2] = Pt.z;
-            const d3 n2 = unit3(n);
+            d3 n2, n3;
+            if (flat) { const double *u = &P.S.prim_units[(size_t)prim * 9]; n2 = ld3(u + 3); n3 = ld3(u + 6); }
+            else { n2 = unit3(n); n3 = unit3(n2); }
             const d3 vv = unit3(sub3(o, Pt));
-            const d3 n3 = unit3(n2);
             h->n[0] = n2.x; h->n[1] = n2.y; h->n[2] = n2.z;
             h->nn[0] = n3.x; h->nn[1] = n3.y; h->nn[2] = n3.z;
             h->v[0] = vv.x; h->v[1] = vv.y; h->v[2] = vv.z;

@@ -314,6 +314,20 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     if ((rc = upload(ctx, s->prim_flags, (size_t)s->n_prims, &D.prim_flags)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->prim_material, (size_t)s->n_prims, &D.prim_material)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->prim_normals, (size_t)s->n_prims * 12, &D.prim_normals)) != RT_OK) return rc;
+    {
+        // successive normalisations of each flat normal, in the reference's arithmetic (v / sqrt(v.v) when v.v > 0)
+        std::vector<double> units((size_t)s->n_prims * 9, 0.0);
+        for (int32_t p = 0; p < s->n_prims; ++p) {
+            if (s->prim_flags[p] & RT_PRIM_SPHERE) continue;
+            double v[3] = {s->prim_normals[(size_t)p * 12], s->prim_normals[(size_t)p * 12 + 1], s->prim_normals[(size_t)p * 12 + 2]};
+            for (int k = 0; k < 3; ++k) {
+                const double z = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+                if (z > 0) { const double q = std::sqrt(z); v[0] = v[0] / q; v[1] = v[1] / q; v[2] = v[2] / q; }
+                units[(size_t)p * 9 + k * 3] = v[0]; units[(size_t)p * 9 + k * 3 + 1] = v[1]; units[(size_t)p * 9 + k * 3 + 2] = v[2];
+            }
+        }
+        if ((rc = upload(ctx, units.data(), units.size(), &D.prim_units)) != RT_OK) return rc;
+    }
     if ((rc = upload(ctx, s->materials, (size_t)s->n_materials, &D.materials)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->lights, (size_t)s->n_lights, &D.lights)) != RT_OK) return rc;
     {

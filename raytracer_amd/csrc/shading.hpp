@@ -7,9 +7,10 @@
 // `best` is a slot of the given record arrays (| SLOT_SPHERE for spheres).
 DEV void hit_geometry(const DevScene &S, const rt_tri_rec *tri_arr, const rt_sph_rec *sph_arr, const uint32_t *sph_prim_arr,
                       uint32_t flags, d3 o, d3 d, double minT, double t, int best, int known_prim, int *prim_out, d3 *n_out,
-                      d3 *P_out)
+                      d3 *P_out, bool *flat_out = nullptr)
 {
     d3 nraw;
+    bool flat = false;
     int prim = known_prim;       // >= 0: the walk already knows it, no need to go through the record
     if (best & SLOT_SPHERE) {
         const int s = best & ~SLOT_SPHERE;
@@ -21,7 +22,9 @@ DEV void hit_geometry(const DevScene &S, const rt_tri_rec *tri_arr, const rt_sph
         if (known_prim < 0) prim = tr->prim;
         const double *pn = &S.prim_normals[(size_t)prim * 12];
         nraw = ld3(pn);
+        flat = true;
         if ((flags & RT_FLAG_PHONG_NORMALS) && (S.prim_flags[prim] & RT_PRIM_HAS_VNORMALS)) {
+            flat = false;
             double al, be;
             (void)tri_test(tr, o, d, minT, 10000000000.0, &al, &be);
             d3 n0 = ld3(pn + 3), n1 = ld3(pn + 6), n2 = ld3(pn + 9);
@@ -29,7 +32,9 @@ DEV void hit_geometry(const DevScene &S, const rt_tri_rec *tri_arr, const rt_sph
         }
     }
     *prim_out = prim;
-    *n_out = unit3(nraw);
+    // a flat triangle's normal is the same at every hit: its normalisations are tabulated at upload
+    if (flat && flat_out) { *n_out = ld3(&S.prim_units[(size_t)prim * 9]); *flat_out = true; }
+    else { *n_out = unit3(nraw); if (flat_out) *flat_out = false; }
     *P_out = mk3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
 }
 
