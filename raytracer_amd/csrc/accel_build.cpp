@@ -48,13 +48,13 @@ struct Box {
     }
 };
 
-int kLeafMax = 2;               // 1..4 (the leaf code keeps count-1 in two bits); 2 measured best: box tests are cheap, FP64 records are not
+constexpr int kLeafMaxDefault = 2;   // 1..4 (the leaf code keeps count-1 in two bits); 2 measured best: box tests are cheap, FP64 records are not
 constexpr int kBins = 16;
 constexpr int kSahDepth = 14;   // below this depth splits are medians, which bounds the tree height
 
 class Builder {
 public:
-    Builder(std::vector<Item> &items, Bvh &out) : it_(items), out_(out) {}
+    Builder(std::vector<Item> &items, Bvh &out, int leaf_max) : it_(items), out_(out), kLeafMax(leaf_max) {}
 
     void run()
     {
@@ -202,6 +202,7 @@ private:
 
     std::vector<Item> &it_;
     Bvh &out_;
+    const int kLeafMax;
 };
 
 }  // namespace
@@ -326,9 +327,10 @@ void collapse(const Bvh &b2, Bvh4 &out)
 void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_tri, std::vector<int32_t> &octree_sph_key)
 {
     out = Accel();
+    int leaf_max = kLeafMaxDefault;
     if (const char *e = std::getenv("RT_LEAF_MAX")) {      // experiments only
         const int v = std::atoi(e);
-        if (v >= 1 && v <= 4) kLeafMax = v;
+        if (v >= 1 && v <= 4) leaf_max = v;
     }
     octree_tri.assign(d.tri, d.tri + d.n_tri_slots);
     octree_sph_key.assign(static_cast<size_t>(d.n_sph_slots), 0);
@@ -378,8 +380,8 @@ void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_t
             sph_items.push_back(it);
         }
     }
-    Builder(tri_items, out.tri_bvh).run();
-    Builder(sph_items, out.sph_bvh).run();
+    Builder(tri_items, out.tri_bvh, leaf_max).run();
+    Builder(sph_items, out.sph_bvh, leaf_max).run();
     out.tri.reserve(tri_items.size());
     for (const Item &it : tri_items) out.tri.push_back(octree_tri[it.src]);
     out.sph.reserve(sph_items.size());
