@@ -317,25 +317,42 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
 
 // Deferred light-camera evaluations of one generation: density query, then the same shading as a
 // lit point with the query result as the factor (Camera.h:444-476).
-// LC_PER_WAVE < 64 spreads a generation's queries over more waves (measured: no gain, the time of a
-// pass is the chain of dependent fetches of its single longest query).
-#ifndef LC_PER_WAVE
-#define LC_PER_WAVE 64
-#endif
-__global__ __launch_bounds__(256) void k_lightcam(FrameParams P, QueueSet Q)
+// Deferred light-camera evaluations of a batch, all six generations in one launch: density query,
+// then the same shading as a lit point with the query result as the factor (Camera.h:444-476).
+// A query is a long chain of dependent fetches and a launch lasts as long as its longest one, so
+// the generations are not given a launch each: their 64-query chunks form one list, dealt round
+// to the waves.
+struct LightcamQueues {
+    const HitRec *deferred[6];
+    uint32_t shard_cap[6];
+    const uint32_t *counts;
+};
+__global__ __launch_bounds__(256) void k_lightcam(FrameParams P, LightcamQueues L)
 {
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
-    const int lane = (int)(threadIdx.x & 63);
-    const int parts = 64 / LC_PER_WAVE;
-    const ShardMap smap = shard_map(&Q.counts[CNT_DEFER(Q.generation)], Q.hit_shard_cap, 1u);
-    for (long long vc = wave; vc < (long long)smap.total * parts; vc += n_waves) {
-        const long long chunk = vc / parts;
-        const int part = (int)(vc - chunk * parts);
+    ShardMap smap[6];
+    long long first[7];
+    first[0] = 0;
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        smap[g] = shard_map(&L.counts[CNT_DEFER(g)], L.shard_cap[g], 1u);
+        first[g + 1] = first[g] + (long long)smap[g].total;
+    }
+    for (long long work = wave; work < first[6]; work += n_waves) {
+        int g = 0;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) if (work >= first[k]) g = k;
+        // the generation is the same for the whole wave; pick its map without indexing registers dynamically
+        ShardMap m = smap[0];
+        const HitRec *base = L.deferred[0];
+        uint32_t cap = L.shard_cap[0];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) if (g == k) { m = smap[k]; base = L.deferred[k]; cap = L.shard_cap[k]; }
         int shard;
-        const int item = shard_locate(smap, (uint32_t)chunk, &shard, part * LC_PER_WAVE + (lane % LC_PER_WAVE));
-        const bool active = item >= 0 && lane < LC_PER_WAVE;
-        const HitRec *hr = &Q.deferred[(size_t)shard * Q.hit_shard_cap + (active ? (uint32_t)item : 0u)];
+        const int item = shard_locate(m, (uint32_t)(work - first[g]), &shard);
+        const bool active = item >= 0;
+        const HitRec *hr = &base[(size_t)shard * cap + (active ? (uint32_t)item : 0u)];
         bool lit = false;
         d3 local = mk3(0, 0, 0);
         const d3 Pt = ld3(hr->P);
@@ -351,11 +368,6 @@ __global__ __launch_bounds__(256) void k_lightcam(FrameParams P, QueueSet Q)
     }
 }
 
-// Light rays of one light camera (LightCam::lightCast, recursiveCastLightRays, castLightRay:
-// LightCam.h:207-306, 340-556).  One lane per sub-pixel (si, sj) of the N x N grid; each lane follows
-// its refraction / total-internal-reflection chain and writes every impact into its own row of
-// `slots` (21 entries: the first hit plus a depth budget of 20), so the host can read them back in
-// the reference's order.
 struct PhotonParams {
     DevScene S;
     double u[3], v[3], w[3], e[3];

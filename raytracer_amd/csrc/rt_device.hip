@@ -73,7 +73,7 @@ struct rt_ctx {
     double *accum = nullptr; size_t accum_values = 0;
     RayRec *rays[2] = {nullptr, nullptr}; size_t ray_capacity[2] = {0, 0};
     HitRec *hits[4] = {nullptr, nullptr, nullptr, nullptr}; size_t hit_capacity[4] = {0, 0, 0, 0};
-    HitRec *deferred = nullptr; size_t deferred_capacity = 0;
+    HitRec *deferred[6] = {}; size_t deferred_capacity[6] = {};   // one per generation: a batch's light-camera queries run in one launch at its end
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_c[6] = {}, ev_s[6] = {}, ev_batch[2] = {};
     uint32_t *counts = nullptr;
@@ -183,10 +183,11 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     (void)hipFree(ctx->rays[0]);
     (void)hipFree(ctx->rays[1]);
     for (HitRec *h : ctx->hits) (void)hipFree(h);
-    (void)hipFree(ctx->deferred);
+    for (int k = 0; k < 6; ++k) (void)hipFree(ctx->deferred[k]);
     for (int k = 0; k < 6; ++k) { (void)hipEventDestroy(ctx->ev_c[k]); (void)hipEventDestroy(ctx->ev_s[k]); }
     for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ctx->ev_batch[k]);
     (void)hipStreamDestroy(ctx->stream2);
+
     (void)hipFree(ctx->counts);
     (void)hipFree(ctx->totals);
     for (void *p : ctx->stage) (void)hipFree(p);
@@ -677,7 +678,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         for (int k = 0; k < (overlap ? 4 : 1); ++k)
             if ((rc = ensure(&ctx->hits[k], &ctx->hit_capacity[k], (size_t)need_hits)) != RT_OK) return rc;
         const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
-        if (use_lightcam && (rc = ensure(&ctx->deferred, &ctx->deferred_capacity, (size_t)need_hits)) != RT_OK) return rc;
+        if (use_lightcam)
+            for (int g = 0; g < 6; ++g)
+                if ((rc = ensure(&ctx->deferred[g], &ctx->deferred_capacity[g], (size_t)(hit_cap[g] * N_SHARDS))) != RT_OK) return rc;
 
         // Two streams.  A: counters memset, closest-hit passes C0..C5 of every batch, in order.
         // B: shadow/shading passes S0..S5 and the batch's counter roll-up.  S_g waits for C_g; C_g+2
@@ -698,7 +701,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.rays_in = ctx->rays[g & 1];
                 Q.rays_out = ctx->rays[(g + 1) & 1];
                 Q.hits = ctx->hits[overlap ? par * 2 + (g & 1) : 0];
-                Q.deferred = ctx->deferred;
+                Q.deferred = ctx->deferred[g];
                 Q.counts = counts;
                 Q.in_shard_cap = (uint32_t)ray_cap[g];
                 Q.out_shard_cap = (uint32_t)(g < 5 ? ray_cap[g + 1] : 0);
@@ -730,12 +733,18 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     if (ev) HIP_TRY(hipEventRecord(ev->first, sb));
                     if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
                     else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
-                    if (use_lightcam) hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks), dim3(256), 0, sb, P, Q);
                     if (ev) HIP_TRY(hipEventRecord(ev->second, sb));
                     HIP_TRY(hipEventRecord(ctx->ev_s[g], sb));
                 }
             }
             HIP_TRY(hipStreamWaitEvent(sb, ctx->ev_c[5], 0));
+            if (use_lightcam) {
+                // the density queries of all six generations in one launch, after the last shadow pass
+                LightcamQueues L{};
+                for (int g = 0; g < 6; ++g) { L.deferred[g] = ctx->deferred[g]; L.shard_cap[g] = (uint32_t)hit_cap[g]; }
+                L.counts = counts;
+                hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks), dim3(256), 0, sb, P, L);
+            }
             hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, sb, counts, ctx->totals, P.S.n_lights);
             HIP_TRY(hipEventRecord(ctx->ev_batch[par], sb));
             ctx->pending_batches++;
