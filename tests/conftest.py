@@ -4,6 +4,14 @@ import sys
 
 import pytest
 
+try:
+    # PyTorch ships its own HIP runtime; when a test uses both, torch has to be the first to load one
+    # (a process that initialised the system runtime through libraytracer_amd.so first leaves torch
+    # without a visible GPU).
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -218,3 +218,33 @@ def test_bad_arguments_are_errors(gpu):
     with pytest.raises(rt.RtError):
         fresh.render(cam)   # no scene uploaded
     fresh.close()
+
+
+def test_async_render_into_device_buffers_and_two_contexts(gpu, oracle_frame):
+    """rt_render_async + rt_sync with torch device buffers; a second context on the same GPU renders
+    another scene in between and neither disturbs the other."""
+    import torch
+    s = load_scene(gpu, "teapot-3")
+    cam = s.camera()
+    u8 = torch.zeros((cam.resy, cam.resx, 3), dtype=torch.uint8, device="cuda")
+    f64 = torch.zeros((cam.resy, cam.resx, 3), dtype=torch.float64, device="cuda")
+    hit = torch.full((cam.resy, cam.resx), -2, dtype=torch.int32, device="cuda")
+    assert gpu.render_device(cam, rgb_f64_ptr=f64.data_ptr(), rgb_u8_ptr=u8.data_ptr(), hit_id_ptr=hit.data_ptr(),
+                             flags=rt.FLAG_KEEP_ZERO_WEIGHT, sync=False) is None
+    with pytest.raises(rt.RtError):            # a frame is in flight: a second one is refused, not queued
+        gpu.render_device(cam, rgb_u8_ptr=u8.data_ptr(), sync=False)
+    other = rt.Renderer(0)
+    s2 = rt.Scene.load("balls")
+    other.upload(s2)
+    g2 = other.render(s2.camera(), flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    st = gpu.sync()
+    with pytest.raises(rt.RtError):
+        gpu.sync()                              # nothing in flight any more
+    o = oracle_frame("teapot-3")
+    assert np.array_equal(u8.cpu().numpy(), o["rgb_u8"])
+    assert np.array_equal(hit.cpu().numpy(), o["hit_id"])
+    assert np.abs(f64.cpu().numpy() - o["rgb_f64"]).max() <= 1e-9
+    assert st["closest_rays"] == o["counters"]["closest_rays"]
+    assert np.array_equal(g2["rgb_u8"], oracle_frame("balls")["rgb_u8"])
+    other.close()
+    s2.close()
