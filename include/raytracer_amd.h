@@ -156,6 +156,8 @@ typedef struct rt_stats {
     uint64_t closest_launches, shadow_launches;
     int32_t batches;
     int32_t queue_overflow;
+    double primary_ms;         /* only with RT_FLAG_TIMING: the share of closest_ms spent in generation 0 */
+    uint64_t primary_launches; /* (ray generation fused with the closest-hit query; one launch per batch) */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -794,11 +794,16 @@ extern "C" int rt_sync(rt_ctx *ctx, rt_stats *stats)
         stats->gpu_ms = ms;
         if (ctx->pending_flags & RT_FLAG_TIMING) {
             double c = 0, s = 0;
+            double prim = 0;
+            uint64_t prim_n = 0;
             for (size_t i = 0; i < ctx->ev_closest_used; ++i) {
                 float m = 0;
                 HIP_TRY(hipEventElapsedTime(&m, ctx->ev_closest[i].first, ctx->ev_closest[i].second));
                 c += m;
+                if (i % 6 == 0) { prim += m; ++prim_n; }      // six closest-hit passes per batch, generation 0 first
             }
+            stats->primary_ms = prim;
+            stats->primary_launches = prim_n;
             for (size_t i = 0; i < ctx->ev_shadow_used; ++i) {
                 float m = 0;
                 HIP_TRY(hipEventElapsedTime(&m, ctx->ev_shadow[i].first, ctx->ev_shadow[i].second));
