@@ -98,3 +98,29 @@ DEV void accum_add_runs(double *accum, bool in_queue, bool valid, uint32_t pixel
     }
 }
 
+// Queue records move as whole 16-byte pieces, all pieces of a record issued together: the compiler,
+// left to the individual fields, splits a record into a dozen narrower accesses placed where each
+// field happens to be used, and the memory pipeline charges per instruction, not per byte
+// (8K x 16 spp frame: 108 -> 97 ms from the stores alone).  (Non-temporal stores were tried for
+// these write-once records and are far slower: 178 ms.)
+typedef double rec_v2d __attribute__((ext_vector_type(2)));
+DEV rec_v2d rec_pack(double a, double b) { rec_v2d v; v.x = a; v.y = b; return v; }
+DEV rec_v2d rec_pack_words(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    rec_v2d v;
+    v.x = __hiloint2double((int)b, (int)a);
+    v.y = __hiloint2double((int)d, (int)c);
+    return v;
+}
+template <int N>
+DEV void rec_store(void *dst, const rec_v2d (&q)[N])
+{
+    __attribute__((address_space(1))) rec_v2d *p = (__attribute__((address_space(1))) rec_v2d *)dst;
+#pragma unroll
+    for (int k = 0; k < N; ++k) p[k] = q[k];
+}
+// piece k of the record at `src`
+DEV rec_v2d rec_load(const void *src, int k)
+{
+    return ((const __attribute__((address_space(1))) rec_v2d *)src)[k];
+}

@@ -102,12 +102,13 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
             const int local = shard_locate(smap, (uint32_t)chunk, &shard);
             active = local >= 0;
             const RayRec *rr = &Q.rays_in[active ? (size_t)shard * Q.in_shard_cap + (uint32_t)local : 0];
-            o = ld3(rr->o);
-            d = ld3(rr->d);
-            A = rr->A;
-            coef = rr->coef;
-            pixel = rr->pixel;
-            meta = rr->meta;
+            const rec_v2d r0 = rec_load(rr, 0), r1 = rec_load(rr, 1), r2 = rec_load(rr, 2), r3 = rec_load(rr, 3), r4 = rec_load(rr, 4);
+            o = mk3(r0.x, r0.y, r1.x);
+            d = mk3(r1.y, r2.x, r2.y);
+            A = r3.x;
+            coef = r3.y;
+            pixel = (uint32_t)__double2loint(r4.x);
+            meta = (uint32_t)__double2hiint(r4.x);
         }
 
         double best_t = 0;
@@ -181,38 +182,27 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
             Q.counts[CNT_OVERFLOW] = 1u;
 
         if (want_hit && slot_h < Q.hit_shard_cap) {
-            HitRec *h = &Q.hits[(size_t)shard * Q.hit_shard_cap + slot_h];
-            h->P[0] = Pt.x; h->P[1] = Pt.y; h->P[2] = Pt.z;
             d3 n2, n3;
             if (flat) { const double *u = &P.S.prim_units[(size_t)prim * 9]; n2 = ld3(u + 3); n3 = ld3(u + 6); }
             else { n2 = unit3(n); n3 = unit3(n2); }
             const d3 vv = unit3(sub3(o, Pt));
-            h->n[0] = n2.x; h->n[1] = n2.y; h->n[2] = n2.z;
-            h->nn[0] = n3.x; h->nn[1] = n3.y; h->nn[2] = n3.z;
-            h->v[0] = vv.x; h->v[1] = vv.y; h->v[2] = vv.z;
-            h->weight = wloc;
-            h->pixel = pixel;
-            h->prim = prim;
-            h->mat = mat;
+            // HitRec: P, n, nn, v, weight, pixel, prim, light, cam, mat, pad
+            const rec_v2d q[8] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, n2.x), rec_pack(n2.y, n2.z), rec_pack(n3.x, n3.y),
+                                  rec_pack(n3.z, vv.x), rec_pack(vv.y, vv.z),
+                                  rec_pack(wloc, __hiloint2double(prim, (int)pixel)), rec_pack_words(0u, 0u, (uint32_t)mat, 0u)};
+            rec_store(&Q.hits[(size_t)shard * Q.hit_shard_cap + slot_h], q);
         }
         if (want_refr && slot_a < Q.out_shard_cap) {
             const d3 rd = refract_dir(d, n, m.ior, false);
-            RayRec *r = &Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_a];
-            r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
-            r->d[0] = rd.x; r->d[1] = rd.y; r->d[2] = rd.z;
-            r->A = A * m.T;
-            r->coef = m.T * coef;
-            r->pixel = pixel;
-            r->meta = (uint32_t)(L - 1) | 0x100u;
+            // RayRec: o, d, A, coef, pixel, meta, pad
+            const rec_v2d q[5] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, rd.x), rec_pack(rd.y, rd.z), rec_pack(A * m.T, m.T * coef),
+                                  rec_pack_words(pixel, (uint32_t)(L - 1) | 0x100u, 0u, 0u)};
+            rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_a], q);
         }
         if (want_refl && slot_b < Q.out_shard_cap) {
-            RayRec *r = &Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_b];
-            r->o[0] = Pt.x; r->o[1] = Pt.y; r->o[2] = Pt.z;
-            r->d[0] = refl.x; r->d[1] = refl.y; r->d[2] = refl.z;
-            r->A = A;
-            r->coef = coef2;
-            r->pixel = pixel;
-            r->meta = (uint32_t)(L - 1);
+            const rec_v2d q[5] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, refl.x), rec_pack(refl.y, refl.z), rec_pack(A, coef2),
+                                  rec_pack_words(pixel, (uint32_t)(L - 1), 0u, 0u)};
+            rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_b], q);
         }
     }
 #ifdef RT_COUNT
@@ -245,9 +235,13 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
         const uint32_t h = active ? (uint32_t)item / nl : 0u;
         const int li = active ? (int)((uint32_t)item - h * nl) : 0;
         const HitRec *hr = &Q.hits[(size_t)shard * Q.hit_shard_cap + h];
-        const d3 Pt = ld3(hr->P);
+        // head of the record: P, weight, pixel, prim, material -- four 16-byte pieces fetched together
+        const rec_v2d h0 = rec_load(hr, 0), h1 = rec_load(hr, 1), h6 = rec_load(hr, 6), h7 = rec_load(hr, 7);
+        const d3 Pt = mk3(h0.x, h0.y, h1.x);
+        const double weight = h6.x;
+        const int hit_prim = __double2hiint(h6.y), hit_mat = __double2loint(h7.y);
         const d3 lpos = ld3(load_light(P.S, li, true).pos);
-        const uint32_t pixel = hr->pixel;
+        const uint32_t pixel = (uint32_t)__double2loint(h6.y);
         bool lit = false;
         int defer_cam = -1;
         d3 local = mk3(0, 0, 0);
@@ -269,11 +263,11 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
 #endif
                     const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
                     WC_ADD(wc, rays);
-                    occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack, wc) ||
-                               bvh_any<false>(P.S, Pt, rd, d2, rb, hr->prim, maxT, stack, wc);
+                    occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc) ||
+                               bvh_any<false>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc);
                 }
             } else {
-                occluded = trace_shadow(P.S, Pt, rd, hr->prim, maxT, cull, &only, &closest);
+                occluded = trace_shadow(P.S, Pt, rd, hit_prim, maxT, cull, &only, &closest);
             }
             if (occluded && only) {
                 // shadowed by transparent spheres only: the light camera of (that sphere, this light)
@@ -287,7 +281,10 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
             lit = !occluded;
             if (lit) {
                 const rt_light lgt = load_light(P.S, li, true);     // read again here rather than kept in registers through the walk
-                local = phong_terms(load_material(P.S, hr->mat, true), hr, &lgt, rd, .999999);
+                // the rest of the record (n, nn, v) in five pieces, also together
+                const rec_v2d g1 = rec_load(hr, 1), g2 = rec_load(hr, 2), g3 = rec_load(hr, 3), g4 = rec_load(hr, 4), g5 = rec_load(hr, 5);
+                local = phong_terms(load_material(P.S, hit_mat, true), mk3(g1.y, g2.x, g2.y), mk3(g3.x, g3.y, g4.x),
+                                    mk3(g4.y, g5.x, g5.y), &lgt, rd, .999999);
             }
         }
         if (!BVH && P.S.lc_table) {
@@ -304,11 +301,12 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
                 if (kfac > .01) {
                     lit = true;
                     const rt_light lgt = load_light(P.S, li, true);
-                    local = phong_terms(load_material(P.S, hr->mat, true), hr, &lgt, unit3(sub3(lpos, Pt)), kfac);
+                    local = phong_terms(load_material(P.S, hit_mat, true), ld3(hr->n), ld3(hr->nn), ld3(hr->v), &lgt,
+                                        unit3(sub3(lpos, Pt)), kfac);
                 }
             }
         }
-        accum_add_runs(P.accum, active, lit, pixel, hr->weight, local);
+        accum_add_runs(P.accum, active, lit, pixel, weight, local);
     }
 #ifdef RT_COUNT
     walk_count_flush(wc, 16);
@@ -361,7 +359,8 @@ __global__ __launch_bounds__(256) void k_lightcam(FrameParams P, LightcamQueues 
             const rt_light *lt = &P.S.lights[hr->light];
             if (kfac > .01) {
                 lit = true;
-                local = phong_terms(load_material(P.S, hr->mat, false), hr, lt, unit3(sub3(ld3(lt->pos), Pt)), kfac);
+                local = phong_terms(load_material(P.S, hr->mat, false), ld3(hr->n), ld3(hr->nn), ld3(hr->v), lt,
+                                    unit3(sub3(ld3(lt->pos), Pt)), kfac);
             }
         }
         accum_add_runs(P.accum, active, lit, hr->pixel, hr->weight, local);

@@ -59,13 +59,11 @@ DEV d3 refract_dir(d3 d, d3 n, double ior, bool renormalize)
 
 // Diffuse + specular terms of one light at one hit (Solid.h:128-172), scaled by `kfac`
 // (Camera.h:465-476).  `rd` is the unit vector from the hit point to the light.
-DEV d3 phong_terms(const rt_material &m, const HitRec *hr, const rt_light *lt, d3 rd, double kfac)
+// `normal`, `nn`, `v`: the hit record's n, nn and v.
+DEV d3 phong_terms(const rt_material &m, d3 normal, d3 nn, d3 v, const rt_light *lt, d3 rd, double kfac)
 {
-    const d3 normal = ld3(hr->n);
     d3 local = mk3(0, 0, 0);
     if (m.Ks > 0) {
-        d3 nn = ld3(hr->nn);
-        d3 v = ld3(hr->v);
         d3 rdir = unit3(add3(neg3(rd), scale3(2.0 * dot3(rd, nn), nn)));
         double a = dot3(rdir, v);
         double pw = pow((a < 0.0) ? 0.0 : a, m.Shine);
