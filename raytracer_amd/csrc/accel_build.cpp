@@ -320,6 +320,20 @@ void collapse(const Bvh &b2, Bvh4 &out)
     if (b2.nodes.empty()) return;
     collapse_node(b2, 0, out, 1);
     breadth_first(out);
+    // Stack bound: going down from a node with k children leaves at most k-1 of them pending.  Children
+    // follow their parent in breadth-first order, so one backward sweep sees every child before its parent.
+    std::vector<int32_t> need(out.nodes.size(), 0);
+    for (size_t i = out.nodes.size(); i-- > 0;) {
+        const Bvh4Node &nd = out.nodes[i];
+        int k = 0, deepest = 0;
+        for (int c = 0; c < 4; ++c) {
+            if (nd.child[c] == -1) continue;
+            ++k;
+            if (nd.child[c] >= 0) deepest = std::max(deepest, need[nd.child[c]]);
+        }
+        need[i] = (k > 0 ? k - 1 : 0) + deepest;
+    }
+    out.max_stack = need[0];
 }
 
 }  // namespace
@@ -392,8 +406,8 @@ void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_t
     }
     collapse(out.tri_bvh, out.tri_bvh4);
     collapse(out.sph_bvh, out.sph_bvh4);
-    // a walk stacks at most three siblings per 4-wide level
-    out.usable = 3 * out.tri_bvh4.max_depth + 1 <= 64 && 3 * out.sph_bvh4.max_depth + 1 <= 64 &&
+    // a walk needs max_stack + 1 entries of its LDS stack
+    out.usable = out.tri_bvh4.max_stack + 1 <= 64 && out.sph_bvh4.max_stack + 1 <= 64 &&
                  out.tri.size() < (1u << 28) && out.sph.size() < (1u << 28);
 }
 

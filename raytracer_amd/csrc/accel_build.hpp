@@ -43,7 +43,8 @@ static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
 
 struct Bvh4 {
     std::vector<Bvh4Node> nodes;  // node 0 is the root; empty when there are no primitives
-    int32_t max_depth = 0;        // in 4-wide nodes; a walk stacks at most 3 siblings per level
+    int32_t max_depth = 0;        // in 4-wide nodes
+    int32_t max_stack = 0;        // most entries a depth-first walk can have pending: siblings left behind on the way down
     double max_abs_coord = 0;     // largest |coordinate| of any box: scales the rounding pad of the slab test
 };
 

@@ -60,7 +60,7 @@ struct rt_ctx {
     bool any_transparent_sphere = false;
     bool spheres_inside_root = true;       // every sphere lies inside the root cube
     bool accel_usable = false;             // hierarchies built and shallow enough for the LDS stack
-    int accel_depth = 0;                   // deepest hierarchy, in nodes: the stack entries a ray can need
+    int accel_stack = 0;                   // deepest hierarchy, in nodes: the stack entries a ray can need
     // host copies needed to set up the light cameras
     std::vector<rt_light> h_lights;
     std::vector<std::array<double, 4>> h_lc_spheres;   // centre + radius of every transparent sphere, by rank
@@ -309,7 +309,7 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
         D.bvh_bound = (float)(bb * 1.000001 + 1e-30);
     }
     ctx->accel_usable = acc.usable;
-    ctx->accel_depth = acc.tri_bvh4.max_depth > acc.sph_bvh4.max_depth ? acc.tri_bvh4.max_depth : acc.sph_bvh4.max_depth;
+    ctx->accel_stack = acc.tri_bvh4.max_stack > acc.sph_bvh4.max_stack ? acc.tri_bvh4.max_stack : acc.sph_bvh4.max_stack;
     if ((rc = upload(ctx, s->sph, (size_t)s->n_sph_slots, &D.sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->sph_prim, (size_t)s->n_sph_slots, &D.sph_prim)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->prim_flags, (size_t)s->n_prims, &D.prim_flags)) != RT_OK) return rc;
@@ -559,8 +559,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     // walk when every sphere is inside the root cube, and for shadow queries only when no
     // transparent sphere exists (checkOccluded3 is then order-free).
     bool bvh_closest_ok = may_cull && ctx->accel_usable;
-    // at most three pending siblings per 4-wide level (BVH_STACK is the cap the builder checks against)
-    int stack_entries = 3 * ctx->accel_depth + 1;
+    // the builder's bound on pending siblings, plus one (BVH_STACK is the cap the builder checks against)
+    int stack_entries = ctx->accel_stack + 1;
     if (stack_entries > BVH_STACK) stack_entries = BVH_STACK;
     if (stack_entries < 4) stack_entries = 4;
     // LDS per block: the stacks, the material and light tables, then as many top-of-tree nodes as fit
