@@ -187,6 +187,13 @@ bool Scene::load(const std::string &path, std::string &err)
             int count = 0;
             cur.word();
             cur.integer(count);
+            // a vertex count that runs past the end of the file is a truncated or corrupt file (the
+            // reference would re-read its last line that many times)
+            if (count > 0 && static_cast<size_t>(count) > lines.size() - li - 1) {
+                err = "polygon at line " + std::to_string(li + 1) + " announces " + std::to_string(count) +
+                      " vertices, the file has fewer lines left: " + path;
+                return false;
+            }
             Ring ring;
             Vec3 p, n;  // a short line keeps the previous values, like a failed stream extraction
             for (int k = 0; k < count; ++k) {

@@ -109,6 +109,17 @@ def test_transparent_triangles_and_mixed_primitives(gpu, tmp_path):
     assert g["stats"]["rays_per_generation"][2] > 0      # reflections of refractions are traced
 
 
+def test_degenerate_primitives(gpu, tmp_path):
+    # zero-area and needle triangles, a zero-radius sphere, coincident duplicates: nothing may trap, and whatever
+    # the reference's arithmetic makes of them (NaN ratios fail every comparison) the device must make of them too
+    body = ("l 4 6 9\nf 0.7 0.7 0.2 0.8 0.3 10 0 1\np 3\n0 0 0\n0 0 0\n0 0 0\np 3\n-1 0 0.2\n1 0 0.2\n3 0 0.2\n"
+            "s 0.5 0.5 0.5 0\np 3\n-2 -2 0\n2 -2 0\n0 2 0\np 3\n-2 -2 0\n2 -2 0\n0 2 0\n"
+            "s 0 0 1 0.5\ns 0 0 1 0.5\np 3\n0 0 0.4\n1e-9 0 0.4\n0 1e-9 0.4\n")
+    g, ref = both(gpu, write_scene(tmp_path, "degenerate", body))
+    check(g, ref)
+    assert (g["hit_id"] >= 0).any()
+
+
 def test_odd_sample_count(gpu, tmp_path):
     body = "l 5 5 9\nf 0.2 0.9 0.3 0.8 0.3 20 0 1\np 3\n-2 -2 0\n2 -2 0\n0 2 0\nf 0.9 0.3 0.2 0.7 0.4 30 0 1\ns 0 0 1 0.7\n"
     g, ref = both(gpu, write_scene(tmp_path, "s3", body), num_samples=3, seed=11)

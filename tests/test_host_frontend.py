@@ -172,3 +172,30 @@ def test_no_gpu_means_an_error_not_a_fallback():
         pytest.skip("a GPU is present")
     with pytest.raises(rt.RtError):
         rt.Renderer(0)
+
+
+HEADER = "b 0 0 0\nv\nfrom 3 3 3\nat 0 0 0\nup 0 0 1\nangle 40\nhither 1\nresolution 8 8\n"
+
+
+def test_malformed_files_are_errors_or_empty_scenes_never_a_hang(tmp_path):
+    def load(name, text):
+        p = tmp_path / name
+        p.write_bytes(text if isinstance(text, bytes) else text.encode())
+        return rt.Scene.load(str(p))
+
+    # a polygon that announces more vertices than the file has lines left (truncated or corrupt file)
+    with pytest.raises(rt.RtError):
+        load("trunc.nff", HEADER + "f 1 1 1 1 0 1 0 1\np 4\n0 0 0\n1 0 0\n")
+    with pytest.raises(rt.RtError):
+        load("huge.nff", HEADER + "p 200000000\n")
+    # nothing usable: an empty scene with resolution 0 x 0 (rendering it is refused by rt_render)
+    for name, text in (("empty.nff", ""), ("noise.nff", bytes(range(256)) * 8), ("half_view.nff", "v\nfrom 1 1 1\nat 0 0 0\n")):
+        s = load(name, text)
+        assert s.desc.n_prims == 0 and s.desc.n_nodes == 1
+        s.close()
+    # degenerate primitives are kept as the reference keeps them: a zero-area triangle, a zero-radius
+    # sphere, a two-vertex "polygon" (dropped: fewer than three vertices), a polygon without an `f` line
+    s = load("degenerate.nff", HEADER + "p 3\n0 0 0\n0 0 0\n0 0 0\nf 1 1 1 1 0 1 0 1\ns 0 0 0 0\np 2\n0 0 0\n1 1 1\n")
+    assert s.desc.n_prims == 2
+    assert s.desc.n_materials == 2          # the all-zero material of the polygon that had no `f` line, then the real one
+    s.close()
