@@ -394,6 +394,13 @@ void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_t
             sph_items.push_back(it);
         }
     }
+    // Geometry the single-precision boxes cannot bound safely -- a NaN or infinite coordinate (which the
+    // reference's tests simply never hit, but which poisons every box above it), or one beyond 10^6 --
+    // keeps the whole scene on the octree walk, whose arithmetic is the reference's in every such case.
+    for (const std::vector<Item> *items : {&tri_items, &sph_items})
+        for (const Item &it : *items)
+            for (int k = 0; k < 3; ++k)
+                if (!(std::fabs(it.lo[k]) < 1e6) || !(std::fabs(it.hi[k]) < 1e6)) return;   // usable stays false
     Builder(tri_items, out.tri_bvh, leaf_max).run();
     Builder(sph_items, out.sph_bvh, leaf_max).run();
     out.tri.reserve(tri_items.size());

@@ -120,6 +120,17 @@ def test_degenerate_primitives(gpu, tmp_path):
     assert (g["hit_id"] >= 0).any()
 
 
+def test_non_finite_and_far_away_coordinates(gpu, tmp_path):
+    # a NaN vertex, an infinite one and a vertex a billion units away: the reference never hits the first two
+    # (every comparison with NaN is false) and treats the third like any other; the device falls back to the
+    # octree walk for such scenes and must agree
+    body = ("l 4 6 9\nf 0.7 0.7 0.2 0.8 0.3 10 0 1\np 3\n-2 -2 0\n2 -2 0\n0 2 0\np 3\nnan 0 0\n1 0 1\n0 1 1\n"
+            "p 3\n0 0 1\ninf 0 1\n0 1 1\np 3\n0 0 0.5\n1e9 0 0.5\n0 1 0.5\ns 0 0 1 0.4\n")
+    g, ref = both(gpu, write_scene(tmp_path, "nonfinite", body))
+    check(g, ref)
+    assert (g["hit_id"] >= 0).any()
+
+
 def test_odd_sample_count(gpu, tmp_path):
     body = "l 5 5 9\nf 0.2 0.9 0.3 0.8 0.3 20 0 1\np 3\n-2 -2 0\n2 -2 0\n0 2 0\nf 0.9 0.3 0.2 0.7 0.4 30 0 1\ns 0 0 1 0.7\n"
     g, ref = both(gpu, write_scene(tmp_path, "s3", body), num_samples=3, seed=11)
