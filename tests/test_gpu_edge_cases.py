@@ -131,6 +131,20 @@ def test_non_finite_and_far_away_coordinates(gpu, tmp_path):
     assert (g["hit_id"] >= 0).any()
 
 
+def test_more_lights_and_materials_than_the_on_chip_tables_hold(gpu, tmp_path):
+    # 18 lights and 70 materials: entries beyond the first 16 / 64 are read from memory instead of LDS
+    rng = np.random.default_rng(5)
+    lines = ["l %.3f %.3f %.3f" % tuple(rng.uniform(3, 9, 3)) for _ in range(18)]
+    for k in range(70):
+        r, g_, b = rng.uniform(0.2, 1, 3)
+        lines.append("f %.3f %.3f %.3f 0.7 0.3 %d 0 1" % (r, g_, b, 5 + k))
+        x, y = (k % 10) * 0.4 - 2, (k // 10) * 0.5 - 1.75
+        lines.append("p 3\n%.3f %.3f 0\n%.3f %.3f 0\n%.3f %.3f 0" % (x, y, x + 0.38, y, x, y + 0.48))
+    g, ref = both(gpu, write_scene(tmp_path, "many", "\n".join(lines) + "\n", res="64 64"))
+    check(g, ref, tol=1e-8)
+    assert len(np.unique(g["hit_id"])) > 60
+
+
 def test_odd_sample_count(gpu, tmp_path):
     body = "l 5 5 9\nf 0.2 0.9 0.3 0.8 0.3 20 0 1\np 3\n-2 -2 0\n2 -2 0\n0 2 0\nf 0.9 0.3 0.2 0.7 0.4 30 0 1\ns 0 0 1 0.7\n"
     g, ref = both(gpu, write_scene(tmp_path, "s3", body), num_samples=3, seed=11)
