@@ -142,14 +142,13 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
         accum_add_runs(P.accum, active, active && !hit, pixel, wloc, ld3(P.S.bg));
 
         // hit record (Solid.h:110-125)
-        d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0), refl = mk3(0, 0, 0);
+        d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0);
         int prim = -1, mat = 0;
         bool flat = false;
         rt_material m;
         m.Ks = 0; m.T = 0; m.ior = 1;
         if (hit) {
             hit_geometry(P.S, tri_arr, sph_arr, sph_prim_arr, P.flags, o, d, .01, best_t, best, best_prim, &prim, &n, &Pt, &flat);
-            refl = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));
             mat = P.S.prim_material[prim];
             m = load_material(P.S, mat, true);
         }
@@ -200,6 +199,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
             rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_a], q);
         }
         if (want_refl && slot_b < Q.out_shard_cap) {
+            const d3 refl = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));      // hr.reflectionDir (Solid.h:121-122), only where a ray follows it
             const rec_v2d q[5] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, refl.x), rec_pack(refl.y, refl.z), rec_pack(A, coef2),
                                   rec_pack_words(pixel, (uint32_t)(L - 1), 0u, 0u)};
             rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_b], q);
