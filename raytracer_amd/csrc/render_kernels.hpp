@@ -33,7 +33,16 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
     // a block none of whose waves gets a chunk leaves before it copies anything into LDS (late
     // generations of small frames fill only a few of the launched blocks)
     if ((long long)blockIdx.x * (blockDim.x >> 6) >= n_chunks) return;
-    fill_node_cache(P.S, BVH);
+    if (PRIMARY && threadIdx.x == 0) {
+        // The camera's 16 doubles go to LDS once per block and are read back per chunk.  As kernel
+        // arguments they would occupy 32 scalar registers for the whole kernel; the scalar file is
+        // already over-subscribed by the scene's pointers, and every value spilled from it costs a
+        // vector instruction each time it is brought back (a seventh of this kernel's vector work).
+        double *cw = reinterpret_cast<double *>(&s_lds[P.S.lds_cam_word]);
+        for (int k = 0; k < 3; ++k) { cw[k] = P.cam.u[k]; cw[3 + k] = P.cam.v[k]; cw[6 + k] = P.cam.w[k]; cw[9 + k] = P.cam.e[k]; }
+        cw[12] = P.cam.d; cw[13] = P.cam.l; cw[14] = P.cam.t; cw[15] = P.cam.pix_width;
+    }
+    fill_node_cache(P.S, BVH);      // ends with the block's barrier
     const bool cull = P.cull_closest != 0;
     WalkCount wc{};
 
@@ -60,7 +69,17 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
             const int i = global_row(P, lrow);
             pixel = (uint32_t)lrow * (uint32_t)P.cam.resx + (uint32_t)j;
             first_sample = (si == 0 && sj == 0);
-            const rt_camera &c = P.cam;
+            struct { double d, l, t, pix_width; int resx; } c;
+            d3 u, v, w, e;
+            {
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                const __attribute__((address_space(3))) v2d *cw =
+                    (const __attribute__((address_space(3))) v2d *)((__attribute__((address_space(3))) const int *)s_lds + P.S.lds_cam_word);
+                const v2d c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3], c4 = cw[4], c5 = cw[5], c6 = cw[6], c7 = cw[7];
+                u = mk3(c0.x, c0.y, c1.x); v = mk3(c1.y, c2.x, c2.y); w = mk3(c3.x, c3.y, c4.x); e = mk3(c4.y, c5.x, c5.y);
+                c.d = c6.x; c.l = c6.y; c.t = c7.x; c.pix_width = c7.y;
+                c.resx = P.cam.resx;
+            }
             const uint32_t gpix = (uint32_t)i * (uint32_t)c.resx + (uint32_t)j;
             const uint32_t sample = (uint32_t)(si * N + sj);
             double p, q, r;
@@ -85,7 +104,6 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
                 q = c.t - i * c.pix_width;
             }
             r = -c.d;
-            d3 u = ld3(c.u), v = ld3(c.v), w = ld3(c.w), e = ld3(c.e);
             d = unit3(add3(add3(scale3(p, u), scale3(q, v)), scale3(r, w)));
             o = e;
             if (P.aperture > 0) {

@@ -576,7 +576,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const size_t lds_tables = (size_t)(P.S.mat_cached + P.S.light_cached) * 64;
     {
         const size_t per_block = ctx->lds_per_cu / 4;
-        const size_t fixed = lds_stack + lds_tables + 512;
+        const size_t fixed = lds_stack + lds_tables + 128 + 512;
         long long room = per_block > fixed ? (long long)((per_block - fixed) / (NODE_LDS_WORDS * 4)) : 0;
         if (const char *e = std::getenv("RT_NODE_CACHE")) room = std::atoll(e) < room ? std::atoll(e) : room;   // experiments
         // the triangle hierarchy first, the sphere hierarchy takes what is left; split evenly when both are large
@@ -592,9 +592,10 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         P.S.sph_cached = (int32_t)ns;
         P.S.lds_cache_word = (int32_t)(lds_stack / sizeof(int));
         P.S.lds_table_word = P.S.lds_cache_word + (P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS;
+        P.S.lds_cam_word = P.S.lds_table_word + (P.S.mat_cached + P.S.light_cached) * 16;
     }
     // every traversal kernel gets the same layout (the octree-walk variants use the tables only)
-    const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int) + lds_tables;
+    const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int) + lds_tables + 128;
     const size_t lds_closest = lds_bvh;
     const size_t lds_shadow = lds_bvh;
 
