@@ -262,6 +262,9 @@ int32_t collapse_node(const Bvh &b2, int32_t idx2, Bvh4 &out, int depth)
         kids.erase(kids.begin() + pick);
         add_children_of(open);
     }
+    // The any-hit walk takes the last hit child first: put the largest box there, it is the likeliest
+    // to hold an occluder (the nearest-hit walk orders children by entry distance and does not care).
+    std::stable_sort(kids.begin(), kids.end(), [](const Child4 &a, const Child4 &b) { return box_area(a) < box_area(b); });
     Bvh4Node nd;
     std::memset(&nd, 0, sizeof nd);
     for (int c = 0; c < 4; ++c) {
