@@ -105,6 +105,14 @@ private:
 
     void set_leaf(BvhNode &nd, int side, int b, int e)
     {
+        // largest box first: an any-hit walk stops at the first occluder it finds
+        std::stable_sort(it_.begin() + b, it_.begin() + e, [](const Item &x, const Item &y) {
+            auto area = [](const Item &i) {
+                const double ex = i.hi[0] - i.lo[0], ey = i.hi[1] - i.lo[1], ez = i.hi[2] - i.lo[2];
+                return ex * ey + ey * ez + ez * ex;
+            };
+            return area(x) > area(y);
+        });
         store_box(nd, side, bounds(b, e));
         nd.child[side] = -2 - (b * 4 + (e - b - 1));   // leaf code: first record and count-1 in two bits
         nd.count[side] = e - b;
