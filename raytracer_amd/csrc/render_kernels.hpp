@@ -455,6 +455,16 @@ __global__ __launch_bounds__(256) void k_photons(PhotonParams Q)
 
 // totals[0]=closest rays, [1]=shadow rays, [2..7]=rays per generation (generation 0 is filled in by the
 // host, which knows the number of primary samples), [8..13]=hits per generation, [15]=overflow
+// Packs the impacts of a photon pass: ray i's first `counts[i] & 0xff` slots go to out[offsets[i]...], ray order kept.
+__global__ __launch_bounds__(256) void k_pack_photons(const lightcam::Point *slots, const int32_t *counts, const uint32_t *offsets,
+                                                      int n_rays, int slots_per_ray, lightcam::Point *out)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_rays) return;
+    const int n = counts[i] & 0xff;
+    for (int k = 0; k < n; ++k) out[offsets[i] + k] = slots[(size_t)i * slots_per_ray + k];
+}
+
 __global__ void k_collect_counts(const uint32_t *counts, unsigned long long *totals, int n_lights)
 {
     const int lane = (int)threadIdx.x;   // one wave, lane = shard

@@ -14,12 +14,14 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/raytracer_amd.h"
@@ -435,9 +437,21 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
         (void)hipFree(d_slots);
         return fail(RT_ERR_DEVICE, "hipMalloc failed for the light-camera counts");
     }
-    std::vector<lightcam::Point> h_slots(n_rays * LC_MAX_IMPACTS);
+    uint32_t *d_offsets = nullptr;
+    if (hipMalloc((void **)&d_offsets, n_rays * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipFree(d_slots);
+        (void)hipFree(d_counts);
+        return fail(RT_ERR_DEVICE, "hipMalloc failed for the light-camera offsets");
+    }
+    std::vector<uint32_t> h_offsets(n_rays);
     std::vector<int32_t> h_counts(n_rays);
     std::vector<DevLightCam> table(n_pairs);
+    struct PairWork {
+        std::vector<lightcam::Point> pts;
+        lightcam::Tree tree;
+        double max_dist = 0, spw = 0, light_pos[3] = {0, 0, 0}, sphere_pos[3] = {0, 0, 0};
+    };
+    std::vector<PairWork> work(n_pairs);
     int rc = RT_OK;
     for (size_t r = 0; r < ctx->h_lc_spheres.size() && rc == RT_OK; ++r)
         for (size_t li = 0; li < ctx->h_lights.size() && rc == RT_OK; ++li) {
@@ -457,50 +471,85 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
             Q.counts = d_counts;
             hipLaunchKernelGGL(k_photons, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, ctx->stream, Q);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
-                hipMemcpy(h_counts.data(), d_counts, n_rays * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
-                hipMemcpy(h_slots.data(), d_slots, h_slots.size() * sizeof(lightcam::Point), hipMemcpyDeviceToHost) != hipSuccess) {
+                hipMemcpy(h_counts.data(), d_counts, n_rays * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
                 rc = fail(RT_ERR_DEVICE, "light-camera photon pass failed");
                 break;
             }
-            std::vector<lightcam::Point> pts;
-            double max_dist = 0;
+            // most rays leave two or three impacts in their 21 slots: pack them on the device (ray order
+            // kept, it is the order the reference inserts them in) and fetch only those
+            size_t n_pts = 0;
             for (size_t i = 0; i < n_rays; ++i) {
-                const int n = h_counts[i] & 0xff;
+                h_offsets[i] = (uint32_t)n_pts;
+                n_pts += (size_t)(h_counts[i] & 0xff);
                 ctx->lc_rays += (unsigned long long)(h_counts[i] >> 8);
-                for (int k = 0; k < n; ++k) {
-                    const lightcam::Point &p = h_slots[i * LC_MAX_IMPACTS + k];
-                    pts.push_back(p);
-                    const double dz = lightcam::length3(p.x, p.y, p.z);
-                    if (dz > max_dist) max_dist = dz;     // std::max(distToOrigin, maxDistFromZero)
+            }
+            std::vector<lightcam::Point> pts(n_pts);
+            if (n_pts) {
+                lightcam::Point *d_packed = nullptr;
+                bool ok = hipMalloc((void **)&d_packed, n_pts * sizeof(lightcam::Point)) == hipSuccess &&
+                          hipMemcpy(d_offsets, h_offsets.data(), n_rays * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+                if (ok) {
+                    hipLaunchKernelGGL(k_pack_photons, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, ctx->stream, d_slots,
+                                       d_counts, d_offsets, (int)n_rays, LC_MAX_IMPACTS, d_packed);
+                    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess &&
+                         hipMemcpy(pts.data(), d_packed, n_pts * sizeof(lightcam::Point), hipMemcpyDeviceToHost) == hipSuccess;
                 }
+                if (d_packed) (void)hipFree(d_packed);
+                if (!ok) { rc = fail(RT_ERR_DEVICE, "light-camera photon pass: packing the impacts failed"); break; }
             }
-            lightcam::Tree tree;
-            lightcam::build(pts, max_dist, tree);
-            DevLightCam cam{};
-            void *dn = nullptr, *dp = nullptr;
-            if (hipMalloc(&dn, sizeof(lightcam::Node) * (tree.nodes.size() ? tree.nodes.size() : 1)) != hipSuccess ||
-                hipMalloc(&dp, sizeof(lightcam::Point) * (tree.points.size() ? tree.points.size() : 1)) != hipSuccess) {
-                if (dn) (void)hipFree(dn);
-                rc = fail(RT_ERR_DEVICE, "hipMalloc failed for a light-camera tree");
-                break;
+            double max_dist = 0;
+            for (const lightcam::Point &p : pts) {
+                const double dz = lightcam::length3(p.x, p.y, p.z);
+                if (dz > max_dist) max_dist = dz;     // std::max(distToOrigin, maxDistFromZero)
             }
-            ctx->lc_allocs.push_back(dn);
-            ctx->lc_allocs.push_back(dp);
-            if (hipMemcpy(dn, tree.nodes.data(), sizeof(lightcam::Node) * tree.nodes.size(), hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(dp, tree.points.data(), sizeof(lightcam::Point) * tree.points.size(), hipMemcpyHostToDevice) != hipSuccess) {
-                rc = fail(RT_ERR_DEVICE, "upload of a light-camera tree failed");
-                break;
-            }
-            cam.nodes = static_cast<const lightcam::Node *>(dn);
-            cam.points = static_cast<const lightcam::Point *>(dp);
-            cam.n_nodes = (int32_t)tree.nodes.size();
-            cam.n_points = (int32_t)tree.points.size();
-            cam.spw = fr.pix_width / N;
-            for (int k = 0; k < 3; ++k) { cam.light_pos[k] = lt.pos[k]; cam.sphere_pos[k] = spos[k]; }
-            table[r * ctx->h_lights.size() + li] = cam;
+            PairWork &pw = work[r * ctx->h_lights.size() + li];
+            pw.pts.swap(pts);
+            pw.max_dist = max_dist;
+            pw.spw = fr.pix_width / N;
+            for (int k = 0; k < 3; ++k) { pw.light_pos[k] = lt.pos[k]; pw.sphere_pos[k] = spos[k]; }
         }
     (void)hipFree(d_slots);
     (void)hipFree(d_counts);
+    (void)hipFree(d_offsets);
+    if (rc != RT_OK) { free_lightcams(ctx); return rc; }
+    {
+        // the point octrees of the pairs are independent: one host thread each (at most eight at a time)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t first = 0; first < n_pairs; first += 8) {
+            std::vector<std::thread> pool;
+            for (size_t k = first; k < n_pairs && k < first + 8; ++k)
+                pool.emplace_back([&work, k]() { lightcam::build(work[k].pts, work[k].max_dist, work[k].tree); });
+            for (std::thread &t : pool) t.join();
+        }
+        if (std::getenv("RT_DEBUG"))
+            fprintf(stderr, "[rt] %zu light-camera trees built in %.1f ms\n", n_pairs,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    for (size_t k = 0; k < n_pairs && rc == RT_OK; ++k) {
+        const lightcam::Tree &tree = work[k].tree;
+        DevLightCam cam{};
+        void *dn = nullptr, *dp = nullptr;
+        if (hipMalloc(&dn, sizeof(lightcam::Node) * (tree.nodes.size() ? tree.nodes.size() : 1)) != hipSuccess ||
+            hipMalloc(&dp, sizeof(lightcam::Point) * (tree.points.size() ? tree.points.size() : 1)) != hipSuccess) {
+            if (dn) (void)hipFree(dn);
+            rc = fail(RT_ERR_DEVICE, "hipMalloc failed for a light-camera tree");
+            break;
+        }
+        ctx->lc_allocs.push_back(dn);
+        ctx->lc_allocs.push_back(dp);
+        if (hipMemcpy(dn, tree.nodes.data(), sizeof(lightcam::Node) * tree.nodes.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dp, tree.points.data(), sizeof(lightcam::Point) * tree.points.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(RT_ERR_DEVICE, "upload of a light-camera tree failed");
+            break;
+        }
+        cam.nodes = static_cast<const lightcam::Node *>(dn);
+        cam.points = static_cast<const lightcam::Point *>(dp);
+        cam.n_nodes = (int32_t)tree.nodes.size();
+        cam.n_points = (int32_t)tree.points.size();
+        cam.spw = work[k].spw;
+        for (int c = 0; c < 3; ++c) { cam.light_pos[c] = work[k].light_pos[c]; cam.sphere_pos[c] = work[k].sphere_pos[c]; }
+        table[k] = cam;
+    }
     if (rc != RT_OK) { free_lightcams(ctx); return rc; }
     void *dt = nullptr;
     HIP_TRY(hipMalloc(&dt, sizeof(DevLightCam) * n_pairs));
