@@ -47,22 +47,27 @@ extern __shared__ __align__(16) int s_lds[];
 #define NODE_LDS_WORDS 36
 DEV void fill_node_cache(const DevScene &S, bool with_nodes)
 {
+    // 16 bytes per thread and trip: a block of a small frame lives about as long as this copy takes
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4i lds_v4i;
+    typedef __attribute__((address_space(1))) const v4i glb_v4i;
+    __attribute__((address_space(3))) int *lds = (__attribute__((address_space(3))) int *)s_lds;
     if (with_nodes) {
-        const int words = (S.tri_cached + S.sph_cached) * 32;
-        const int *tsrc = reinterpret_cast<const int *>(S.tri_nodes);
-        const int *ssrc = reinterpret_cast<const int *>(S.sph_nodes);
-        for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) {
-            const int node = i >> 5, w = i & 31;
-            const int v = node < S.tri_cached ? tsrc[i] : ssrc[i - S.tri_cached * 32];
-            s_lds[S.lds_cache_word + node * NODE_LDS_WORDS + w] = v;
+        const int pieces = (S.tri_cached + S.sph_cached) * 8;
+        glb_v4i *tsrc = (glb_v4i *)S.tri_nodes;
+        glb_v4i *ssrc = (glb_v4i *)S.sph_nodes;
+        for (int i = (int)threadIdx.x; i < pieces; i += (int)blockDim.x) {
+            const int node = i >> 3, q = i & 7;
+            const v4i v = node < S.tri_cached ? tsrc[i] : ssrc[i - S.tri_cached * 8];
+            *(lds_v4i *)(lds + (S.lds_cache_word + node * NODE_LDS_WORDS + q * 4)) = v;
         }
     }
     // material and light tables (64 bytes per entry): every hit reads one of each, always the same few
-    const int mwords = S.mat_cached * 16, lwords = S.light_cached * 16;
-    const int *msrc = reinterpret_cast<const int *>(S.materials);
-    const int *lsrc = reinterpret_cast<const int *>(S.lights);
-    for (int i = (int)threadIdx.x; i < mwords + lwords; i += (int)blockDim.x)
-        s_lds[S.lds_table_word + i] = i < mwords ? msrc[i] : lsrc[i - mwords];
+    const int mpieces = S.mat_cached * 4, lpieces = S.light_cached * 4;
+    glb_v4i *msrc = (glb_v4i *)S.materials;
+    glb_v4i *lsrc = (glb_v4i *)S.lights;
+    for (int i = (int)threadIdx.x; i < mpieces + lpieces; i += (int)blockDim.x)
+        *(lds_v4i *)(lds + (S.lds_table_word + i * 4)) = i < mpieces ? msrc[i] : lsrc[i - mpieces];
     __syncthreads();
 }
 
