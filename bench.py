@@ -49,6 +49,14 @@ BAND_ROWS = 16
 NODE_B, TRI_B, SPH_B, QUEUE_B = 64, 96, 32, 192
 
 
+# Per-ray test counts of the reference's traversal on the default workload, as the CPU sample of a
+# one-GPU run measures them (32 rows spread over the frame); used for the roofline object of runs that
+# do not take the CPU sample themselves (N > 1, --no-cpu-baseline).
+RECORDED_BYTES_PER_RAY = {
+    "teapot3_8k16": {"closest": 41.75074814500611 * NODE_B + 217.95551503359582 * TRI_B + QUEUE_B,
+                     "shadow": 36.538628432664986 * NODE_B + 199.73884823610032 * TRI_B + QUEUE_B},
+}
+
 CPU_SAMPLE_TARGET = 4_000_000      # primary samples in the CPU sample (about 12 M rays, 10-30 s of CPU work)
 
 
@@ -250,8 +258,8 @@ def main():
             cpu = cpu_reference_sample(scene_name, resx, resy, N, threads,
                                        lightcam=not (args.flags & rt.FLAG_NO_LIGHTCAM))
         roofline = None
-        if cpu is not None:
-            bpr = cpu["bytes_per_ray"]
+        bpr = cpu["bytes_per_ray"] if cpu is not None else RECORDED_BYTES_PER_RAY.get(args.workload)
+        if bpr is not None:
             # three kernels do the work; the one with the largest total time is the dominant one
             classes = {
                 "k_closest<true, true>": ("closest", kt["primary_ms"], kt["primary_launches"], kt["primary_rays"]),
@@ -265,7 +273,8 @@ def main():
             launches = max(launches, 1)
             bytes_total = rays_k * bpr[dom]
             achieved = bytes_total / (ms_total * 1e-3) / 1e9 if ms_total > 0 else 0.0
-            tr = measured_traffic(args.workload, kname)
+            # (for N > 1 the launches, their rays and their times are rank 0's own; the counter passes are one-GPU runs)
+            tr = measured_traffic(args.workload, kname) if world == 1 else None
             roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": tr["bytes_per_launch"] if tr else None,
                         "traffic_detail": tr,
