@@ -66,7 +66,12 @@ DEV d3 phong_terms(const rt_material &m, d3 normal, d3 nn, d3 v, const rt_light 
     if (m.Ks > 0) {
         d3 rdir = unit3(add3(neg3(rd), scale3(2.0 * dot3(rd, nn), nn)));
         double a = dot3(rdir, v);
-        double pw = pow((a < 0.0) ? 0.0 : a, m.Shine);
+        // pow(max(a, 0), Shine) (Solid.h:166-169).  Behind the mirror direction the base is +0 and the
+        // value follows from the exponent alone; pow() itself costs as much as the rest of this function
+        // and neighbouring lanes are mostly on the same side, so whole waves skip it.
+        double pw;
+        if (a < 0.0) pw = m.Shine > 0.0 ? 0.0 : (m.Shine == 0.0 ? 1.0 : (m.Shine < 0.0 ? __builtin_inf() : m.Shine));
+        else pw = pow(a, m.Shine);
         double ik = lt->intensity * m.Ks;
         d3 comp = mk3((ik * lt->color[0]) * pw, (ik * lt->color[1]) * pw, (ik * lt->color[2]) * pw);
         local = add3(local, scale3(kfac, comp));
