@@ -274,11 +274,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
                 // no transparent sphere in the scene: "occluded" is "any hit", and never "only transparent"
                 const double d2 = dot3(rd, rd);
                 occluded = false;
-#ifdef RT_EXP_SHADOW_SKIP          /* experiment: cost of the kernel without the traversal */
-                if (false) {
-#else
                 if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
-#endif
                     const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
                     WC_ADD(wc, rays);
                     occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc) ||

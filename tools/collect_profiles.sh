@@ -18,5 +18,6 @@ cp $out/trace_teapot3/k_kernel_stats.csv $out/kernel_stats_teapot3.csv
 tools/pmc_passes.sh $tag --workload teapot3_8k16 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_log.txt 2>&1 || { tail -5 $out/pmc_log.txt; exit 1; }
 cp gpurun_out/pmc_${tag}_summary.txt $out/pmc_summary_teapot3_8k16.txt
 cp gpurun_out/pmc_${tag}.json $out/pmc_teapot3_8k16.json
+tools/pmc_quick.sh ${tag}q --workload teapot3_8k16 --steps 1 --warmup 0 --no-cpu-baseline > $out/units_teapot3_8k16.txt 2>&1 || { tail -5 $out/units_teapot3_8k16.txt; exit 1; }
 rm -rf $out/trace_8k16 $out/trace_teapot3
 ls $out
