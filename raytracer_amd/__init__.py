@@ -290,10 +290,13 @@ def part_row_indices(resy, band_rows=0, n_parts=1, part=0):
 class Renderer:
     """One GPU context (rt_ctx)."""
 
+    created = 0      # contexts made by this process so far (a process that has made one has initialised the GPU)
+
     def __init__(self, device=0):
         self._ctx = C.c_void_p()
         _check(load().rt_create(device, C.byref(self._ctx)))
         self.device = device
+        Renderer.created += 1
 
     def close(self):
         if self._ctx:
