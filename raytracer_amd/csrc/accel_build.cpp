@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -49,6 +50,7 @@ struct Box {
 };
 
 constexpr int kLeafMaxDefault = 2;   // 1..4 (the leaf code keeps count-1 in two bits); 2 measured best: box tests are cheap, FP64 records are not
+constexpr int kSplitBudgetPercent = 100;   // growth allowed to split_references()
 constexpr int kBins = 16;
 constexpr int kSahDepth = 14;   // below this depth splits are medians, which bounds the tree height
 
@@ -114,8 +116,17 @@ private:
             return area(x) > area(y);
         });
         store_box(nd, side, bounds(b, e));
-        nd.child[side] = -2 - (b * 4 + (e - b - 1));   // leaf code: first record and count-1 in two bits
-        nd.count[side] = e - b;
+        // two pieces of one primitive in the same leaf: the record is tested once (the second copy stays in
+        // the array behind the leaf's range, unreferenced)
+        int count = e - b;
+        for (int i = b + 1; i < b + count;) {
+            bool dup = false;
+            for (int j = b; j < i; ++j) dup = dup || it_[j].src == it_[i].src;
+            if (dup) { std::rotate(it_.begin() + i, it_.begin() + i + 1, it_.begin() + b + count); --count; }
+            else ++i;
+        }
+        nd.child[side] = -2 - (b * 4 + (count - 1));   // leaf code: first record and count-1 in two bits
+        nd.count[side] = count;
     }
 
     int choose_split(int b, int e, int depth)
@@ -212,6 +223,155 @@ private:
     Bvh &out_;
     const int kLeafMax;
 };
+
+// ---- reference splitting ----
+// A long triangle that lies obliquely in space has a box far larger than itself, and every ray
+// through that box pays for an exact test.  Before the tree is built such triangles are
+// represented by several items: the triangle is cut by axis-aligned planes and each piece gets
+// the (tight) box of its own part.  All pieces point to the same record, so a query still sees
+// the same primitive with the same result; a primitive found through two pieces is the same
+// (t, key) candidate twice.  The pieces' boxes cover the triangle, which is all the walk needs.
+// A triangle cut by axis-aligned planes is a convex polygon of at most 9 corners.
+struct Poly {
+    double p[12][3];
+    int n = 0;
+    void add(const double *x) { if (n < 12) { p[n][0] = x[0]; p[n][1] = x[1]; p[n][2] = x[2]; ++n; } }
+};
+struct Piece {
+    Poly poly;        // the part of the triangle inside the item's box
+    Item item;
+    double gain = 0;  // box area the best cut of this piece saves (0: do not cut)
+};
+
+Box poly_bounds(const Poly &poly)
+{
+    Box b;
+    b.reset();
+    for (int i = 0; i < poly.n; ++i) b.grow(poly.p[i], poly.p[i]);
+    return b;
+}
+
+// The part of a convex polygon with coordinate `axis` <= at (keep_low) or >= at.
+void clip_poly(const Poly &poly, int axis, double at, bool keep_low, Poly &out)
+{
+    out.n = 0;
+    for (int i = 0; i < poly.n; ++i) {
+        const double *a = poly.p[i], *b = poly.p[(i + 1) % poly.n];
+        const bool ia = keep_low ? a[axis] <= at : a[axis] >= at;
+        const bool ib = keep_low ? b[axis] <= at : b[axis] >= at;
+        if (ia) out.add(a);
+        if (ia != ib) {
+            const double t = (at - a[axis]) / (b[axis] - a[axis]);
+            double x[3];
+            for (int k = 0; k < 3; ++k) x[k] = a[k] + t * (b[k] - a[k]);
+            x[axis] = at;
+            out.add(x);
+        }
+    }
+}
+
+void set_item_box(Item &it, const Box &b)
+{
+    for (int k = 0; k < 3; ++k) { it.lo[k] = b.lo[k]; it.hi[k] = b.hi[k]; it.c[k] = 0.5 * (b.lo[k] + b.hi[k]); }
+}
+
+// Halves of `p` on either side of the middle of its box's longest axis; false when there is nothing to cut.
+bool cut_piece(const Piece &p, Piece &lo, Piece &hi)
+{
+    int axis = 0;
+    for (int k = 1; k < 3; ++k) if (p.item.hi[k] - p.item.lo[k] > p.item.hi[axis] - p.item.lo[axis]) axis = k;
+    const double at = 0.5 * (p.item.lo[axis] + p.item.hi[axis]);
+    if (!(at > p.item.lo[axis]) || !(at < p.item.hi[axis])) return false;
+    clip_poly(p.poly, axis, at, true, lo.poly);
+    clip_poly(p.poly, axis, at, false, hi.poly);
+    if (lo.poly.n < 3 || hi.poly.n < 3) return false;
+    lo.item = hi.item = p.item;
+    set_item_box(lo.item, poly_bounds(lo.poly));
+    set_item_box(hi.item, poly_bounds(hi.poly));
+    return true;
+}
+
+double item_area(const Item &it)
+{
+    Box b;
+    for (int k = 0; k < 3; ++k) { b.lo[k] = it.lo[k]; b.hi[k] = it.hi[k]; }
+    return b.area();
+}
+
+// Cuts, most profitable first, until the items have grown by `budget_percent` or no cut saves at
+// least `kMinSaving` of a box; the result replaces `items` only if it pays for the scene as a whole.  (A cut that saves less -- an axis-aligned right triangle saves a
+// quarter -- makes the tree larger for little.)
+void split_references(std::vector<Item> &items, const rt_tri_rec *records, int budget_percent)
+{
+    constexpr double kMinSaving = 0.3, kMinTotalSaving = 0.25;
+    const size_t budget = items.size() * static_cast<size_t>(budget_percent) / 100;
+    if (budget == 0) return;
+    auto prepare = [&](Piece &p) {
+        Piece a, b;
+        p.gain = 0;
+        if (!cut_piece(p, a, b)) return;
+        const double whole = item_area(p.item), parts = item_area(a.item) + item_area(b.item);
+        if (whole > 0 && parts <= (1 - kMinSaving) * whole) p.gain = whole - parts;
+    };
+    // pieces that may still be cut wait in `pool`, ordered through a heap of (gain, index)
+    std::vector<Piece> pool;
+    std::vector<std::pair<double, size_t>> heap;
+    std::vector<Item> done;
+    done.reserve(items.size() + budget);
+    auto whole_piece = [&](const Item &it) {
+        const rt_tri_rec &r = records[it.src];
+        Piece p;
+        p.item = it;
+        for (int k = 0; k < 3; ++k) { p.poly.p[0][k] = r.v0[k]; p.poly.p[1][k] = r.v0[k] - r.ab[k]; p.poly.p[2][k] = r.v0[k] - r.ac[k]; }
+        p.poly.n = 3;
+        prepare(p);
+        return p;
+    };
+    // the first cut of every triangle already tells a compact mesh from a scene of slivers
+    double first_gain = 0, whole_area = 0;
+    for (const Item &it : items) {
+        whole_area += item_area(it);
+        first_gain += whole_piece(it).gain;
+    }
+    if (first_gain < 0.5 * kMinTotalSaving * whole_area) return;
+    for (const Item &it : items) {
+        const Piece p = whole_piece(it);
+        if (p.gain > 0) { heap.emplace_back(p.gain, pool.size()); pool.push_back(p); }
+        else done.push_back(it);
+    }
+    std::make_heap(heap.begin(), heap.end());
+    size_t extra = 0;
+    while (!heap.empty() && extra < budget) {
+        std::pop_heap(heap.begin(), heap.end());
+        const size_t at = heap.back().second;
+        heap.pop_back();
+        const Piece p = pool[at];
+        Piece half[2];
+        if (!cut_piece(p, half[0], half[1])) { done.push_back(p.item); continue; }
+        ++extra;
+        for (int h = 0; h < 2; ++h) {
+            prepare(half[h]);
+            if (half[h].gain <= 0) { done.push_back(half[h].item); continue; }
+            size_t slot = pool.size();
+            if (h == 0) { slot = at; pool[at] = half[h]; }      // the parent's place is free
+            else pool.push_back(half[h]);
+            heap.emplace_back(half[h].gain, slot);
+            std::push_heap(heap.begin(), heap.end());
+        }
+    }
+    for (const auto &e : heap) done.push_back(pool[e.second].item);
+    // Summed box area is what the number of exact tests of a random ray is proportional to.  The cut is
+    // kept only where it removes a good part of it (gears.nff, whose faces are fans of slivers: 64 %);
+    // on compact meshes (the teapots: 9-10 %) the larger tree costs more than the tighter boxes save.
+    double before = 0, after = 0;
+    for (const Item &it : items) before += item_area(it);
+    for (const Item &it : done) after += item_area(it);
+    const bool keep = after <= (1 - kMinTotalSaving) * before;
+    if (std::getenv("RT_DEBUG"))
+        std::fprintf(stderr, "[rt] reference splitting: %zu -> %zu items, box area %.4g -> %.4g (%.1f %% saved): %s\n", items.size(),
+                     done.size(), before, after, before > 0 ? 100 * (before - after) / before : 0.0, keep ? "kept" : "dropped");
+    if (keep) items.swap(done);
+}
 
 }  // namespace
 
@@ -412,6 +572,9 @@ void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_t
         for (const Item &it : *items)
             for (int k = 0; k < 3; ++k)
                 if (!(std::fabs(it.lo[k]) < 1e6) || !(std::fabs(it.hi[k]) < 1e6)) return;   // usable stays false
+    int split_budget = kSplitBudgetPercent;
+    if (const char *e = std::getenv("RT_SPLIT_BUDGET")) split_budget = std::max(0, std::atoi(e));      // experiments only
+    split_references(tri_items, d.tri, split_budget);
     Builder(tri_items, out.tri_bvh, leaf_max).run();
     Builder(sph_items, out.sph_bvh, leaf_max).run();
     out.tri.reserve(tri_items.size());

@@ -76,6 +76,25 @@ def polygons(rng, out):
         out.append("p %d\n%s\n" % (k, "\n".join(fmt(p) for p in pts)))
 
 
+def gear_faces(rng, out):
+    """Many-cornered toothed outlines in an oblique plane: ear clipping turns each into a fan of long slivers,
+    the case the hierarchy builder cuts into pieces."""
+    for _ in range(int(rng.integers(1, 4))):
+        k = 2 * int(rng.integers(6, 15))
+        c = rng.uniform(-2.5, 2.5, 3)
+        u = rng.normal(0, 1, 3)
+        u /= np.linalg.norm(u)
+        v = np.cross(u, rng.normal(0, 1, 3))
+        v /= np.linalg.norm(v)
+        r_out = rng.uniform(1.0, 3.0)
+        r_in = r_out * rng.uniform(0.7, 0.95)
+        ang = np.arange(k) * (2 * np.pi / k)
+        if rng.random() < 0.5:
+            ang = ang[::-1]
+        pts = [c + (r_out if i % 2 else r_in) * (np.cos(a) * u + np.sin(a) * v) for i, a in enumerate(ang)]
+        out.append("p %d\n%s\n" % (k, "\n".join(fmt(p) for p in pts)))
+
+
 def patches(rng, out):
     for _ in range(int(rng.integers(1, 8))):
         c = rng.uniform(-3, 3, 3)
@@ -111,7 +130,7 @@ def random_scene(seed, transparent_spheres, lightcam_samples=None):
             where[2] = rng.uniform(4, 10)              # the first one above the floor, for the caustics
         lights.append(where)
         out.append("l %s\n" % fmt(where))
-    makers = [height_field, loose_triangles, polygons, patches]
+    makers = [height_field, loose_triangles, polygons, patches, gear_faces]
     for _ in range(int(rng.integers(2, 7))):
         out.append(material(rng, transparent=rng.random() < 0.25))
         makers[int(rng.integers(0, len(makers)))](rng, out)
