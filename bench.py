@@ -41,6 +41,7 @@ WORKLOADS = {
     "balls2": ("balls2", 0, 0, 1, 20, 3),
 }
 HBM_PEAK_GBPS = 8000.0
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4      # 256 CUs x 4 SIMDs at 2.4 GHz, a 64-wide instruction occupies a SIMD for 4 clocks
 BAND_ROWS = 16
 
 # Algorithmic bytes per ray (fixed by the reference's traversal, not by what this build fetches):
@@ -120,7 +121,7 @@ def measured_traffic(workload, kernel):
     with open(files[-1]) as f:
         js = json.load(f)
     n = rd = wr = 0.0
-    hit = req = valu = wait = cyc = 0.0
+    hit = req = valu = wait = cyc = insts = 0.0
     for name, e in js.items():
         if not name.startswith(kernel) or "hbm_read_bytes_per_launch" not in e:
             continue
@@ -132,12 +133,14 @@ def measured_traffic(workload, kernel):
         valu += e["counters"].get("SQ_ACTIVE_INST_VALU", 0.0)
         wait += e["counters"].get("SQ_WAIT_ANY", 0.0)
         cyc += e["counters"].get("SQ_WAVE_CYCLES", 0.0)
+        insts += e["counters"].get("SQ_INSTS_VALU", 0.0)
     if n == 0:
         return None
     return {"bytes_per_launch": (rd + wr) / n, "read": rd / n, "write": wr / n, "launches": int(n),
             "l2_hit_rate": hit / req if req else None,
             "valu_issue_share_of_wave_cycles": valu / cyc if cyc else None,
             "waiting_share_of_wave_cycles": wait / cyc if cyc else None,
+            "valu_instructions_per_launch": insts / n if insts else None,
             "source": os.path.relpath(files[-1], ROOT)}
 
 
@@ -287,6 +290,12 @@ def main():
                         "algorithmic_bytes_per_ray": bpr[dom], "rays_per_launch": rays_k / launches,
                         "kernel_ms_per_frame": {k: v[1] / prof_steps for k, v in classes.items()},
                         "frame_gpu_ms": kt["gpu_ms"] / prof_steps}
+            if tr and tr.get("valu_instructions_per_launch"):
+                # the limit that is actually near: wave-level vector instructions (counter pass) over the live launch
+                # time, against one instruction per SIMD every four clocks
+                rate = tr["valu_instructions_per_launch"] / (ms_total / launches * 1e-3) / 1e9
+                roofline["vector_issue"] = {"achieved": rate, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instructions/s",
+                                            "frac": rate / VALU_PEAK_GINSTR}
         line = {
             "metric": "Mrays/sec (primary+secondary)",
             "value": rays / elapsed / 1e6,
