@@ -421,15 +421,24 @@ static std::pair<hipEvent_t, hipEvent_t> *next_event_pair(std::vector<std::pair<
 // point octree on the host (lightcam_build.cpp), flattened tree back to the device.  The reference
 // creates a camera the first time a shading point needs it (Camera.h:417-440); a camera depends
 // only on its pair, so building all of them ahead changes no pixel.
-#define LC_MAX_PAIRS 64
+// All cameras are built ahead, so their number is bounded: by LC_MAX_PAIRS, and by memory -- a light
+// ray leaves about three weighted points, and a point costs about 64 bytes with its share of the tree;
+// the cameras may take a quarter of the free device memory.  Beyond either bound the term stays off and
+// the affected pixels are only marked in the light-camera mask.
+#define LC_MAX_PAIRS 4096
 static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
 {
     free_lightcams(ctx);
     const size_t n_pairs = ctx->h_lc_spheres.size() * ctx->h_lights.size();
-    if (n_pairs == 0 || n_pairs > LC_MAX_PAIRS) return RT_OK;   // beyond the cap the term stays off (masked)
+    if (n_pairs == 0 || n_pairs > LC_MAX_PAIRS) return RT_OK;
     const int N = ctx->lightcam_samples;
     if (N < 1 || N > 4096) return fail(RT_ERR_INVALID, "light camera sample count (Z) must be in 1..4096");
     const size_t n_rays = (size_t)N * N;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if ((double)n_pairs * (double)n_rays * 3.0 * 64.0 > 0.25 * (double)free_b) return RT_OK;
+    }
     lightcam::Point *d_slots = nullptr;
     int32_t *d_counts = nullptr;
     HIP_TRY(hipMalloc((void **)&d_slots, n_rays * LC_MAX_IMPACTS * sizeof(lightcam::Point)));
@@ -451,10 +460,17 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
         lightcam::Tree tree;
         double max_dist = 0, spw = 0, light_pos[3] = {0, 0, 0}, sphere_pos[3] = {0, 0, 0};
     };
-    std::vector<PairWork> work(n_pairs);
+    // Eight pairs at a time: their photon passes one after the other on the device, their point octrees
+    // side by side on host threads (the trees are independent), then the uploads.
+    constexpr size_t kGroup = 8;
+    std::vector<PairWork> work(kGroup);
     int rc = RT_OK;
-    for (size_t r = 0; r < ctx->h_lc_spheres.size() && rc == RT_OK; ++r)
-        for (size_t li = 0; li < ctx->h_lights.size() && rc == RT_OK; ++li) {
+    double build_ms = 0;
+    const size_t n_lights = ctx->h_lights.size();
+    for (size_t first = 0; first < n_pairs && rc == RT_OK; first += kGroup) {
+        const size_t last = first + kGroup < n_pairs ? first + kGroup : n_pairs;
+        for (size_t pair = first; pair < last && rc == RT_OK; ++pair) {
+            const size_t r = pair / n_lights, li = pair % n_lights;
             const auto &sp = ctx->h_lc_spheres[r];
             const rt_light &lt = ctx->h_lights[li];
             lightcam::Frame fr;
@@ -502,54 +518,51 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
                 const double dz = lightcam::length3(p.x, p.y, p.z);
                 if (dz > max_dist) max_dist = dz;     // std::max(distToOrigin, maxDistFromZero)
             }
-            PairWork &pw = work[r * ctx->h_lights.size() + li];
+            PairWork &pw = work[pair - first];
             pw.pts.swap(pts);
             pw.max_dist = max_dist;
             pw.spw = fr.pix_width / N;
             for (int k = 0; k < 3; ++k) { pw.light_pos[k] = lt.pos[k]; pw.sphere_pos[k] = spos[k]; }
         }
+        if (rc != RT_OK) break;
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<std::thread> pool;
+            for (size_t k = 0; k < last - first; ++k)
+                pool.emplace_back([&work, k]() { lightcam::build(work[k].pts, work[k].max_dist, work[k].tree); });
+            for (std::thread &t : pool) t.join();
+            build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        for (size_t k = 0; k < last - first && rc == RT_OK; ++k) {
+            const lightcam::Tree &tree = work[k].tree;
+            DevLightCam cam{};
+            void *dn = nullptr, *dp = nullptr;
+            if (hipMalloc(&dn, sizeof(lightcam::Node) * (tree.nodes.size() ? tree.nodes.size() : 1)) != hipSuccess ||
+                hipMalloc(&dp, sizeof(lightcam::Point) * (tree.points.size() ? tree.points.size() : 1)) != hipSuccess) {
+                if (dn) (void)hipFree(dn);
+                rc = fail(RT_ERR_DEVICE, "hipMalloc failed for a light-camera tree");
+                break;
+            }
+            ctx->lc_allocs.push_back(dn);
+            ctx->lc_allocs.push_back(dp);
+            if (hipMemcpy(dn, tree.nodes.data(), sizeof(lightcam::Node) * tree.nodes.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(dp, tree.points.data(), sizeof(lightcam::Point) * tree.points.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                rc = fail(RT_ERR_DEVICE, "upload of a light-camera tree failed");
+                break;
+            }
+            cam.nodes = static_cast<const lightcam::Node *>(dn);
+            cam.points = static_cast<const lightcam::Point *>(dp);
+            cam.n_nodes = (int32_t)tree.nodes.size();
+            cam.n_points = (int32_t)tree.points.size();
+            cam.spw = work[k].spw;
+            for (int c = 0; c < 3; ++c) { cam.light_pos[c] = work[k].light_pos[c]; cam.sphere_pos[c] = work[k].sphere_pos[c]; }
+            table[first + k] = cam;
+        }
+    }
     (void)hipFree(d_slots);
     (void)hipFree(d_counts);
     (void)hipFree(d_offsets);
-    if (rc != RT_OK) { free_lightcams(ctx); return rc; }
-    {
-        // the point octrees of the pairs are independent: one host thread each (at most eight at a time)
-        const auto t0 = std::chrono::steady_clock::now();
-        for (size_t first = 0; first < n_pairs; first += 8) {
-            std::vector<std::thread> pool;
-            for (size_t k = first; k < n_pairs && k < first + 8; ++k)
-                pool.emplace_back([&work, k]() { lightcam::build(work[k].pts, work[k].max_dist, work[k].tree); });
-            for (std::thread &t : pool) t.join();
-        }
-        if (std::getenv("RT_DEBUG"))
-            fprintf(stderr, "[rt] %zu light-camera trees built in %.1f ms\n", n_pairs,
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    }
-    for (size_t k = 0; k < n_pairs && rc == RT_OK; ++k) {
-        const lightcam::Tree &tree = work[k].tree;
-        DevLightCam cam{};
-        void *dn = nullptr, *dp = nullptr;
-        if (hipMalloc(&dn, sizeof(lightcam::Node) * (tree.nodes.size() ? tree.nodes.size() : 1)) != hipSuccess ||
-            hipMalloc(&dp, sizeof(lightcam::Point) * (tree.points.size() ? tree.points.size() : 1)) != hipSuccess) {
-            if (dn) (void)hipFree(dn);
-            rc = fail(RT_ERR_DEVICE, "hipMalloc failed for a light-camera tree");
-            break;
-        }
-        ctx->lc_allocs.push_back(dn);
-        ctx->lc_allocs.push_back(dp);
-        if (hipMemcpy(dn, tree.nodes.data(), sizeof(lightcam::Node) * tree.nodes.size(), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dp, tree.points.data(), sizeof(lightcam::Point) * tree.points.size(), hipMemcpyHostToDevice) != hipSuccess) {
-            rc = fail(RT_ERR_DEVICE, "upload of a light-camera tree failed");
-            break;
-        }
-        cam.nodes = static_cast<const lightcam::Node *>(dn);
-        cam.points = static_cast<const lightcam::Point *>(dp);
-        cam.n_nodes = (int32_t)tree.nodes.size();
-        cam.n_points = (int32_t)tree.points.size();
-        cam.spw = work[k].spw;
-        for (int c = 0; c < 3; ++c) { cam.light_pos[c] = work[k].light_pos[c]; cam.sphere_pos[c] = work[k].sphere_pos[c]; }
-        table[k] = cam;
-    }
+    if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rt] %zu light-camera trees built in %.1f ms of host time\n", n_pairs, build_ms);
     if (rc != RT_OK) { free_lightcams(ctx); return rc; }
     void *dt = nullptr;
     HIP_TRY(hipMalloc(&dt, sizeof(DevLightCam) * n_pairs));

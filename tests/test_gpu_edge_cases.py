@@ -145,6 +145,23 @@ def test_more_lights_and_materials_than_the_on_chip_tables_hold(gpu, tmp_path):
     assert len(np.unique(g["hit_id"])) > 60
 
 
+def test_many_light_cameras(gpu, tmp_path, oracle_mod):
+    # 40 transparent spheres x 3 lights = 120 (sphere, light) cameras, built ahead on the device side,
+    # where the reference builds only those a shading point asks for: same pixels either way
+    rng = np.random.default_rng(11)
+    body = ["Z 24\n", "l 2 3 12\nl -6 1 10\nl 0 -7 11\n", "f 0.8 0.8 0.7 0.9 0.1 5 0 1\np 4\n-9 -9 0\n9 -9 0\n9 9 0\n-9 9 0\n",
+            "f 0.9 0.9 1.0 0.1 0.3 40 0.85 1.4\n"]
+    for _ in range(40):
+        x, y = rng.uniform(-6, 6, 2)
+        body.append("s %.17g %.17g %.17g %.17g\n" % (x, y, rng.uniform(1.2, 4.0), rng.uniform(0.3, 0.7)))
+    path = write_scene(tmp_path, "manycams", "".join(body), frm="14 12 16", res="96 80")
+    g, ref = both(gpu, path)
+    check(g, ref, tol=1e-6)
+    assert np.array_equal(g["lightcam_mask"], ref["lightcam_mask"])
+    assert g["lightcam_mask"].sum() > 100
+    assert ref["counters"]["lightcam_queries"] > 100
+
+
 def test_odd_sample_count(gpu, tmp_path):
     body = "l 5 5 9\nf 0.2 0.9 0.3 0.8 0.3 20 0 1\np 3\n-2 -2 0\n2 -2 0\n0 2 0\nf 0.9 0.3 0.2 0.7 0.4 30 0 1\ns 0 0 1 0.7\n"
     g, ref = both(gpu, write_scene(tmp_path, "s3", body), num_samples=3, seed=11)
