@@ -61,6 +61,9 @@ struct DevScene {
     float bvh_bound;                      // largest |coordinate| of any hierarchy box
     // light cameras (LightCam.h): one per (transparent sphere, light) pair, index rank*n_lights+light
     const int32_t *prim_lc_rank;          // per primitive: rank among transparent spheres, or -1
+    const rt_sph_rec *tsph;               // the transparent spheres, by rank, and their primitive ids: the only
+    const int32_t *tsph_prim;             //   primitives that make a shadow query depend on the visiting order
+    int32_t n_tsph;
     const struct DevLightCam *lc_table;   // null until the cameras are built
 };
 

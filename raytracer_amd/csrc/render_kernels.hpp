@@ -2,7 +2,7 @@
 //   k_closest<PRIMARY>  ray generation (Camera.h:112-230) fused with the closest-hit query, the hit
 //                       record (Solid.h:110-125) and secondary-ray spawning (Camera.h:232-314)
 //   k_closest<queued>   the same for generations 1..5, rays read from the queue
-//   k_shadow            one item per (hit, light): shadow query (Octree.h:1198-1264), Phong terms
+//   k_shadow, k_shadow_hybrid   one item per (hit, light): shadow query (Octree.h:1198-1264), Phong terms
 //                       (Camera.h:365-488), FP64 accumulation into the frame
 //   k_lightcam          deferred light-camera density queries (Camera.h:406-451)
 //   k_photons           a light camera's photon pass (LightCam.h:207-556)
@@ -232,9 +232,17 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
 #ifndef RT_MIN_WAVES_SHADOW
 #define RT_MIN_WAVES_SHADOW 4
 #endif
-template <bool BVH>
-__global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams P, QueueSet Q)
+// The shadow/shading pass.  MODE selects how the occlusion query is answered: SHADOW_EXACT walks the
+// octree in the reference's order, SHADOW_BVH takes the hierarchies (scenes without transparent spheres),
+// SHADOW_HYBRID decides per ray.
+#define SHADOW_EXACT 0
+#define SHADOW_BVH 1
+#define SHADOW_HYBRID 2
+#define MAX_HYBRID_SPHERES 64
+template <int MODE>
+DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
 {
+    constexpr bool BVH = MODE != SHADOW_EXACT;      // the hierarchies (and their LDS stacks and node cache) are in use
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -270,8 +278,17 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
             bool only = false;
             int closest = -1;
             bool occluded;
-            if (BVH) {
-                // no transparent sphere in the scene: "occluded" is "any hit", and never "only transparent"
+            bool order_free = MODE == SHADOW_BVH;
+            if (MODE == SHADOW_HYBRID) {
+                // checkOccluded3 depends on the visiting order only through transparent spheres the ray hits
+                // (Octree.h:1222-1243); a ray that hits none of them is blocked iff it hits anything
+                const double d2 = dot3(rd, rd);
+                order_free = true;
+                for (int k = 0; k < P.S.n_tsph; ++k)
+                    if (P.S.tsph_prim[k] != hit_prim && sph_test(&P.S.tsph[k], Pt, rd, d2, .01, maxT) < maxT) order_free = false;
+            }
+            if (order_free) {
+                // no transparent sphere in the way: "occluded" is "any hit", and never "only transparent"
                 const double d2 = dot3(rd, rd);
                 occluded = false;
                 if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
@@ -280,8 +297,10 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
                     occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc) ||
                                bvh_any<false>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc);
                 }
-            } else {
+            } else if (MODE != SHADOW_BVH) {
                 occluded = trace_shadow(P.S, Pt, rd, hit_prim, maxT, cull, &only, &closest);
+            } else {
+                occluded = false;
             }
             if (occluded && only) {
                 // shadowed by transparent spheres only: the light camera of (that sphere, this light)
@@ -301,7 +320,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
                                     mk3(g4.y, g5.x, g5.y), &lgt, rd, .999999);
             }
         }
-        if (!BVH && P.S.lc_table) {
+        if (MODE != SHADOW_BVH && P.S.lc_table) {
             bool ok;
             const bool want = defer_cam >= 0;
             const uint32_t slot = wave_reserve(want, &Q.counts[CNT_DEFER(Q.generation)], Q.hit_shard_cap, &Q.counts[CNT_OVERFLOW + 1], &ok);
@@ -327,8 +346,16 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams
 #endif
 }
 
-// Deferred light-camera evaluations of one generation: density query, then the same shading as a
-// lit point with the query result as the factor (Camera.h:444-476).
+template <bool BVH>
+__global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams P, QueueSet Q)
+{
+    shadow_pass<BVH ? SHADOW_BVH : SHADOW_EXACT>(P, Q);
+}
+__global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow_hybrid(FrameParams P, QueueSet Q)
+{
+    shadow_pass<SHADOW_HYBRID>(P, Q);
+}
+
 // Deferred light-camera evaluations of a batch, all six generations in one launch: density query,
 // then the same shading as a lit point with the query result as the factor (Camera.h:444-476).
 // A query is a long chain of dependent fetches and a launch lasts as long as its longest one, so

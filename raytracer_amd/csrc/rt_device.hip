@@ -344,6 +344,17 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
             ctx->h_lc_spheres.push_back({s->sph[i].center[0], s->sph[i].center[1], s->sph[i].center[2], s->sph[i].radius});
         }
         if ((rc = upload(ctx, rank.data(), rank.size(), &D.prim_lc_rank)) != RT_OK) return rc;
+        std::vector<rt_sph_rec> tsph(ctx->h_lc_spheres.size());
+        std::vector<int32_t> tsph_prim(ctx->h_lc_spheres.size());
+        for (int32_t p = 0; p < s->n_prims; ++p)
+            if (rank[p] >= 0) {
+                const auto &c = ctx->h_lc_spheres[rank[p]];
+                tsph[rank[p]] = rt_sph_rec{{c[0], c[1], c[2]}, c[3]};
+                tsph_prim[rank[p]] = p;
+            }
+        if ((rc = upload(ctx, tsph.data(), tsph.size(), &D.tsph)) != RT_OK) return rc;
+        if ((rc = upload(ctx, tsph_prim.data(), tsph_prim.size(), &D.tsph_prim)) != RT_OK) return rc;
+        D.n_tsph = static_cast<int32_t>(tsph.size());
         ctx->h_lights.assign(s->lights, s->lights + s->n_lights);
     }
     D.lc_table = nullptr;
@@ -633,6 +644,10 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     if (lds_stack + 8192 > 64 * 1024) bvh_closest_ok = false;
     if (!bvh_closest_ok) lds_stack = 0;
     const bool bvh_shadow_ok = bvh_closest_ok && !ctx->any_transparent_sphere;
+    // With a few transparent spheres a shadow ray is first tested against those alone: a ray that touches none
+    // of them has an order-free answer and takes the hierarchies; only the others walk the octree.
+    const bool hybrid_shadow = bvh_closest_ok && ctx->any_transparent_sphere && P.S.n_tsph <= MAX_HYBRID_SPHERES &&
+                               !(o->flags & RT_FLAG_NO_CULL);
     P.S.mat_cached = ctx->n_materials < 64 ? ctx->n_materials : 64;
     P.S.light_cached = P.S.n_lights < 16 ? P.S.n_lights : 16;
     const size_t lds_tables = (size_t)(P.S.mat_cached + P.S.light_cached) * 64;
@@ -795,6 +810,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                         return fail(RT_ERR_DEVICE, "hipEventCreate failed");
                     if (ev) HIP_TRY(hipEventRecord(ev->first, sb));
                     if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
+                    else if (hybrid_shadow) hipLaunchKernelGGL(k_shadow_hybrid, dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
                     else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
                     if (ev) HIP_TRY(hipEventRecord(ev->second, sb));
                     HIP_TRY(hipEventRecord(ctx->ev_s[g], sb));
