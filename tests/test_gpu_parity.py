@@ -248,3 +248,40 @@ def test_async_render_into_device_buffers_and_two_contexts(gpu, oracle_frame):
     assert np.array_equal(g2["rgb_u8"], oracle_frame("balls")["rgb_u8"])
     other.close()
     s2.close()
+
+
+def test_context_reuse_across_scenes_sizes_and_modes(gpu, oracle_frame):
+    """One context through a sequence a long-running host would produce: scenes replaced, frame sizes going up and
+    down, the normal-interpolation flag toggled on a scene with light cameras (they see it and are rebuilt), a frame
+    left in flight when its context is destroyed.  Every frame must equal the one a fresh context renders."""
+    import torch
+    ctx = rt.Renderer(0)
+    with pytest.raises(rt.RtError):
+        ctx.render(rt.Scene.load("tetra-3").camera())            # nothing uploaded yet
+    seq = [("balls", (96, 96), 0), ("glass3", (120, 100), 0), ("glass3", (60, 50), rt.FLAG_PHONG_NORMALS), ("glass3", (120, 100), 0),
+           ("teapot-3", (200, 160), rt.FLAG_PHONG_NORMALS), ("tetra-3", (64, 64), 0), ("balls", (96, 96), 0)]
+    current = None
+    for name, res, flags in seq:
+        s = _SCENE_CACHE.setdefault(name, rt.Scene.load(name))
+        if name != current:
+            ctx.upload(s)
+            current = name
+        a = ctx.render(s.camera(*res), flags=flags)
+        fresh = rt.Renderer(0)
+        fresh.upload(s)
+        b = fresh.render(s.camera(*res), flags=flags)
+        fresh.close()
+        assert np.array_equal(a["hit_id"], b["hit_id"]), (name, res)
+        assert np.array_equal(a["rgb_u8"], b["rgb_u8"]), (name, res)
+        assert np.abs(a["rgb_f64"] - b["rgb_f64"]).max() <= 1e-9, (name, res)   # the order of the atomic sums is free
+        assert np.array_equal(a["lightcam_mask"], b["lightcam_mask"]), (name, res)
+    o = oracle_frame("balls", res=(96, 96))
+    assert np.array_equal(a["rgb_u8"], o["rgb_u8"])
+    # a frame in flight when the context goes away: the library waits for it, nothing is written afterwards
+    s = _SCENE_CACHE["balls"]
+    cam = s.camera(512, 512)
+    u8 = torch.zeros((cam.resy, cam.resx, 3), dtype=torch.uint8, device="cuda")
+    ctx.render_device(cam, rgb_u8_ptr=u8.data_ptr(), sync=False)
+    ctx.close()
+    torch.cuda.synchronize()
+    assert np.array_equal(u8.cpu().numpy(), oracle_frame("balls")["rgb_u8"])
