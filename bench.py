@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     #  name: (scene, resx, resy, N, default steps, default warmup)
-    "teapot3_8k16": ("teapot-3", 7680, 4320, 4, 3, 1),
+    "teapot3_8k16": ("teapot-3", 7680, 4320, 4, 10, 2),
     "teapot3": ("teapot-3", 0, 0, 1, 50, 5),
     "balls": ("balls", 0, 0, 1, 50, 5),
     "refract": ("refract", 0, 0, 1, 50, 5),
