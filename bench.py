@@ -15,6 +15,9 @@ Workloads (BASELINE.json `configs`):
     balls         balls.nff 512x512, 1 spp
     refract       refract.nff 512x512, 1 spp
     glass         glass.nff 900x900, 1 spp (light-camera caustics on; the reference's hide.ppm frame)
+    glass_setup   the same, with the scene uploaded again in every step: the frame then includes what the
+                  reference also does once per run -- hierarchies, the four light cameras' photon passes
+                  (231,361 light rays each) and their point octrees
     gears         gears.nff 512x512, 1 spp (36 k triangles, transparent materials, 5 lights)
     balls2        balls2.nff 512x512, 1 spp (every ray reflects to the depth limit)
 
@@ -37,6 +40,7 @@ WORKLOADS = {
     "balls": ("balls", 0, 0, 1, 50, 5),
     "refract": ("refract", 0, 0, 1, 50, 5),
     "glass": ("glass", 0, 0, 1, 20, 3),
+    "glass_setup": ("glass", 0, 0, 1, 5, 1),
     "gears": ("gears", 0, 0, 1, 20, 3),
     "balls2": ("balls2", 0, 0, 1, 20, 3),
 }
@@ -209,6 +213,8 @@ def main():
         frame_no[0] += 1
         if gathered[k] is not None:
             gathered[k].synchronize()
+        if args.workload.endswith("_setup"):
+            gpu.upload(scene)
         st = gpu.render_device(cam, rgb_u8_ptr=render_bufs[k].data_ptr(), num_samples=N, flags=flags, band_rows=band,
                                n_parts=world, part=rank)
         if world > 1:

@@ -478,6 +478,7 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
     int rc = RT_OK;
     double build_ms = 0;
     const size_t n_lights = ctx->h_lights.size();
+    std::vector<std::thread> pool;
     for (size_t first = 0; first < n_pairs && rc == RT_OK; first += kGroup) {
         const size_t last = first + kGroup < n_pairs ? first + kGroup : n_pairs;
         for (size_t pair = first; pair < last && rc == RT_OK; ++pair) {
@@ -534,16 +535,16 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
             pw.max_dist = max_dist;
             pw.spw = fr.pix_width / N;
             for (int k = 0; k < 3; ++k) { pw.light_pos[k] = lt.pos[k]; pw.sphere_pos[k] = spos[k]; }
+            // the tree of this pair is built on a host thread while the device runs the next pair's photon pass
+            pool.emplace_back([&pw]() { lightcam::build(pw.pts, pw.max_dist, pw.tree); });
         }
-        if (rc != RT_OK) break;
         {
             const auto t0 = std::chrono::steady_clock::now();
-            std::vector<std::thread> pool;
-            for (size_t k = 0; k < last - first; ++k)
-                pool.emplace_back([&work, k]() { lightcam::build(work[k].pts, work[k].max_dist, work[k].tree); });
             for (std::thread &t : pool) t.join();
+            pool.clear();
             build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
+        if (rc != RT_OK) break;
         for (size_t k = 0; k < last - first && rc == RT_OK; ++k) {
             const lightcam::Tree &tree = work[k].tree;
             DevLightCam cam{};
@@ -573,7 +574,7 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
     (void)hipFree(d_slots);
     (void)hipFree(d_counts);
     (void)hipFree(d_offsets);
-    if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rt] %zu light-camera trees built in %.1f ms of host time\n", n_pairs, build_ms);
+    if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rt] %zu light-camera trees: %.1f ms waiting for the host threads after the photon passes\n", n_pairs, build_ms);
     if (rc != RT_OK) { free_lightcams(ctx); return rc; }
     void *dt = nullptr;
     HIP_TRY(hipMalloc(&dt, sizeof(DevLightCam) * n_pairs));
