@@ -6,7 +6,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 R=$PWD
 export TMPDIR=/tmp
-for w in teapot3_8k16 teapot3 balls refract glass gears balls2; do
+for w in teapot3_8k16 teapot3 balls refract glass glass_setup gears balls2; do
   timeout -k 10 400 python bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err || { echo "bench $w failed"; tail -3 $out/bench_$w.err; exit 1; }
 done
 cd /tmp
