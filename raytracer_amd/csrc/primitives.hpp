@@ -81,14 +81,18 @@ DEV double tri_test_fast(const TriOps &tr, d3 o, d3 d, double minT, double maxT,
     const double detA = ab.x * m1 + ac.x * m2 + d.x * m3;
     const double m4 = d.y * ae.z - ae.y * d.z;
     const double m5 = ae.y * ac.z - ac.y * ae.z;
-    const double m6 = ab.y * ae.z - ae.y * ab.z;
     const double X = ae.x * m1 + ac.x * m4 + d.x * m5;          // det3(ae, ac, d)
+    const double ad = fabs(detA);
+    const bool ranged = ad > 1e-150 && ad < 1e150;
+    const double sX = detA < 0 ? -X : X;
+    // When the first barycentric coordinate alone rules the triangle out for every lane of the wave that is
+    // testing one, the other two determinants are not formed (neighbouring rays mostly agree on that).
+    if (__ballot(!(ranged && fabs(X) < 1e150 && (sX < -1e-150 || sX > ad * (1.0 + 0x1p-40)))) == 0) return maxT;
+    const double m6 = ab.y * ae.z - ae.y * ab.z;
     const double Y = ab.x * (-m4) + ae.x * m2 + d.x * m6;       // det3(ab, ae, d)
     const double Z = ab.x * (-m5) + ac.x * (-m6) + ae.x * m3;   // det3(ab, ac, ae)
-    const double ad = fabs(detA);
-    if (ad > 1e-150 && ad < 1e150) {
-        const double sg = detA < 0 ? -1.0 : 1.0;
-        const double sX = sg * X, sY = sg * Y, sZ = sg * Z;
+    if (ranged) {
+        const double sY = detA < 0 ? -Y : Y, sZ = detA < 0 ? -Z : Z;
         const double up = ad * (1.0 + 0x1p-40);
         bool miss = (sX < -1e-150) || (sX > up) || (sY < -1e-150) || (sX + sY > ad * (1.0 + 0x1p-30)) ||
                     (sZ < (minT * ad) * (1.0 - 0x1p-40)) || (sZ > (tcut * ad) * (1.0 + 0x1p-40));
