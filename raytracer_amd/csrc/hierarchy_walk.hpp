@@ -225,6 +225,14 @@ DEV int bvh4_step(const accel::Bvh4Node *nodes, int cached, int lds_word, int cu
     int c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3];
     const float inf = __builtin_inff();
     if (ordered) {
+        // no lane of the wave has two hit children: nothing to order, nothing to stack
+        const int nh = (k0 < inf) + (k1 < inf) + (k2 < inf) + (k3 < inf);
+        if (__ballot(nh >= 2) == 0) {
+            if (nh) return k0 < inf ? c0 : (k1 < inf ? c1 : (k2 < inf ? c2 : c3));
+            if (sp == 0) return BVH_NONE;
+            --sp;
+            return stack[sp * 256];
+        }
         BVH_SORT2(k0, c0, k1, c1);
         BVH_SORT2(k2, c2, k3, c3);
         BVH_SORT2(k0, c0, k2, c2);
