@@ -106,9 +106,9 @@ DEV rt_light load_light(const DevScene &S, int index, bool lds)
 // through a per-ray byte offset and no min/max per axis is needed.
 //
 // The test must never reject a box the exact ray touches.  The boxes are already rounded outward.
-// Spatial errors (the origin converted to float, the product origin * (1/d) -- each at most
-// 2^-24 (|o| + pad) once divided by |1/d|) are covered by moving the origin by `pad`, eight times
-// that, away from each plane: lower bounds are taken against o + pad, upper bounds against
+// Spatial errors (the origin converted to float, the product origin * (1/d), the sum with
+// pad * |1/d| -- each at most 2^-24 (|o| + pad) once divided by |1/d|) are covered by moving the
+// origin by `pad`, eight times that, away from each plane: lower bounds are taken against o + pad, upper bounds against
 // o - pad, which is the box grown by pad.  Relative errors (1/d: conversion and division; the
 // rounding of the fused operation) are a few 2^-24 of t and are covered by the factor 1 + 2^-17
 // on tf in the comparison.
@@ -118,31 +118,38 @@ struct RayBox4 {
     float cfx, cfy, cfz;     // (origin moved away from the far plane) * (1 / direction)
     uint32_t sx, sy, sz;     // byte offset of the near planes of an axis in a node: 0 (lower) or 16 (upper) + 32 * axis
 };
-DEV float inv_dir(double d)
-{
-    // an (almost) axis-parallel ray is nudged for the box test only: 0 * inf would be NaN
-    const float df = (float)d;
-    const float dd = fabsf(df) < 1e-25f ? (d < 0 ? -1e-25f : 1e-25f) : df;
-    return __builtin_amdgcn_rcpf(dd);   // one ulp: inside the relative slack of the comparison
-}
 DEV RayBox4 make_raybox4(d3 o, d3 d, float bound)
 {
     RayBox4 r;
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
     const float pad = 0x1p-21f * (omax + bound);
-    r.ix = inv_dir(d.x); r.iy = inv_dir(d.y); r.iz = inv_dir(d.z);
-    const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
-    r.sx = nx ? 16u : 0u; r.sy = ny ? 48u : 32u; r.sz = nz ? 80u : 64u;
-    // lower bounds pair with o + pad, upper bounds with o - pad
-    r.cnx = (nx ? ox - pad : ox + pad) * r.ix; r.cfx = (nx ? ox + pad : ox - pad) * r.ix;
-    r.cny = (ny ? oy - pad : oy + pad) * r.iy; r.cfy = (ny ? oy + pad : oy - pad) * r.iy;
-    r.cnz = (nz ? oz - pad : oz + pad) * r.iz; r.cfz = (nz ? oz + pad : oz - pad) * r.iz;
-    if (!(omax < 1e12f)) {
-        // an origin this far away would overflow the products: let every box pass instead
-        r.ix = r.iy = r.iz = 0.0f;
-        r.cnx = r.cny = r.cnz = 1.0f;
-        r.cfx = r.cfy = r.cfz = -3.0e38f;
+    float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    // an (almost) axis-parallel ray is nudged for the box test only: 0 * inf would be NaN.  Rare, so the
+    // fix-up sits behind a test the whole wave makes at once.
+    if (__ballot(fabsf(dx) < 1e-25f || fabsf(dy) < 1e-25f || fabsf(dz) < 1e-25f)) {
+        if (fabsf(dx) < 1e-25f) dx = d.x < 0 ? -1e-25f : 1e-25f;
+        if (fabsf(dy) < 1e-25f) dy = d.y < 0 ? -1e-25f : 1e-25f;
+        if (fabsf(dz) < 1e-25f) dz = d.z < 0 ? -1e-25f : 1e-25f;
+    }
+    // one ulp each: inside the relative slack of the comparison
+    r.ix = __builtin_amdgcn_rcpf(dx); r.iy = __builtin_amdgcn_rcpf(dy); r.iz = __builtin_amdgcn_rcpf(dz);
+    r.sx = r.ix < 0.0f ? 16u : 0u; r.sy = r.iy < 0.0f ? 48u : 32u; r.sz = r.iz < 0.0f ? 80u : 64u;
+    // Lower bounds pair with o + pad and upper bounds with o - pad; the near plane of an axis is the lower bound
+    // for a positive direction and the upper one for a negative direction, so in both cases
+    // near: (o +- pad) * (1/d) = o * (1/d) + pad * |1/d|,  far: o * (1/d) - pad * |1/d|.
+    const float px = ox * r.ix, py = oy * r.iy, pz = oz * r.iz;
+    const float ax = pad * fabsf(r.ix), ay = pad * fabsf(r.iy), az = pad * fabsf(r.iz);
+    r.cnx = px + ax; r.cfx = px - ax;
+    r.cny = py + ay; r.cfy = py - ay;
+    r.cnz = pz + az; r.cfz = pz - az;
+    if (__ballot(!(omax < 1e12f))) {
+        if (!(omax < 1e12f)) {
+            // an origin this far away would overflow the products: let every box pass instead
+            r.ix = r.iy = r.iz = 0.0f;
+            r.cnx = r.cny = r.cnz = 1.0f;
+            r.cfx = r.cfy = r.cfz = -3.0e38f;
+        }
     }
     return r;
 }
