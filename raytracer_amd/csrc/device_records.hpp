@@ -75,6 +75,23 @@ struct DevLightCam {
     double light_pos[3], sphere_pos[3];
 };
 
+// Division of 32-bit unsigned numbers by a divisor fixed per launch, as a multiplication (Granlund and
+// Montgomery's round-up method): for d >= 2 with l = ceil(log2 d), magic = floor(2^32 (2^l - d) / d) + 1 and
+// q = (t + ((n - t) >> 1)) >> (l - 1), t = high word of magic * n, is floor(n / d) for every 32-bit n.
+struct FastDiv {
+    uint32_t d, magic, shift;
+};
+inline FastDiv make_fastdiv(uint32_t d)
+{
+    FastDiv f{d, 0u, 0u};
+    if (d < 2) return f;
+    uint32_t l = 0;
+    while (l < 32 && (1ull << l) < d) ++l;
+    f.magic = static_cast<uint32_t>((((1ull << l) - d) << 32) / d + 1);
+    f.shift = l - 1;
+    return f;
+}
+
 struct FrameParams {
     DevScene S;
     rt_camera cam;
@@ -83,6 +100,7 @@ struct FrameParams {
     uint32_t flags, seed;
     int32_t band_rows, n_parts, part, local_rows;
     int32_t blocks_x;            // 8x8-pixel blocks per row of blocks (primary sample ordering)
+    FastDiv div_spp, div_blocks_x, div_n, div_band;   // by N*N, blocks_x, N, band_rows
     int32_t cull_closest, cull_shadow;
     double *accum;               // local_rows*resx*3
     int32_t *hit_id;             // local_rows*resx or null
@@ -107,7 +125,10 @@ struct QueueSet {
     uint32_t *counts;
     uint32_t in_shard_cap, out_shard_cap, hit_shard_cap;   // records per shard
     int32_t generation;
-    int64_t chunk_begin, chunk_end;  // PRIMARY only: 64-sample chunks of the primary ordering
+    int64_t chunk_begin, chunk_end;  // PRIMARY only: 64-sample chunks of the primary ordering; a batch begins at a
+                                     // block of 8x8 pixels (chunk_begin is a multiple of N*N)
+    int64_t block_row0;              // PRIMARY only: row and column, in 8x8-pixel blocks, of the batch's first block
+    int32_t block_col0;
 };
 
 // A found primitive is named by its record slot: a triangle slot, or a sphere slot with this bit set.

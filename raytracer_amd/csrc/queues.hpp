@@ -4,9 +4,16 @@
 #include "device_math.hpp"
 #include "device_records.hpp"
 
+DEV uint32_t fast_div(uint32_t n, const FastDiv &f)
+{
+    if (f.d < 2) return n;          // the divisor is the same for every lane
+    const uint32_t t = __umulhi(f.magic, n);
+    return (t + ((n - t) >> 1)) >> f.shift;
+}
+
 DEV int global_row(const FrameParams &P, int local_row)
 {
-    int band = local_row / P.band_rows;
+    int band = (int)fast_div((uint32_t)local_row, P.div_band);
     int within = local_row - band * P.band_rows;
     return (band * P.n_parts + P.part) * P.band_rows + within;
 }

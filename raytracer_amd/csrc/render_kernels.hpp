@@ -55,16 +55,22 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, Qu
         if (PRIMARY) {
             // Primary ordering: pixels in 8x8 blocks (row-major inside a block), the N*N samples of a
             // pixel in consecutive positions; a wave takes 64 consecutive positions.
+            // Positions are counted from the batch's first block, which keeps them in 32 bits, and every
+            // division is by a number fixed for the launch (a multiplication, see FastDiv).
             const int N = P.N;
-            const long long pos = (Q.chunk_begin + chunk) * 64 + lane;
-            const int spp = N * N;
-            const long long pseq = pos / spp;
-            const int smp = (int)(pos - pseq * spp);
-            const long long blk = pseq >> 6;
-            const int within = (int)(pseq & 63);
-            const int by = (int)(blk / P.blocks_x), bx = (int)(blk - (long long)by * P.blocks_x);
-            const int j = bx * 8 + (within & 7), lrow = by * 8 + (within >> 3);
-            const int si = smp / N, sj = smp - si * N;
+            const uint32_t rel = (uint32_t)chunk * 64u + (uint32_t)lane;
+            const uint32_t spp = (uint32_t)(N * N);
+            const uint32_t pseq = fast_div(rel, P.div_spp);              // pixel, counted from the batch's first
+            const int smp = (int)(rel - pseq * spp);
+            const int within = (int)(pseq & 63u);
+            const uint32_t col = (uint32_t)Q.block_col0 + (pseq >> 6);   // block column, not yet wrapped into the row
+            const uint32_t wraps = fast_div(col, P.div_blocks_x);
+            const int bx = (int)(col - wraps * (uint32_t)P.blocks_x);
+            const long long by = Q.block_row0 + wraps;
+            const int j = bx * 8 + (within & 7);
+            const long long lrow_ll = by * 8 + (within >> 3);
+            const int lrow = lrow_ll < P.local_rows ? (int)lrow_ll : P.local_rows;     // beyond the part: inactive below
+            const int si = (int)fast_div((uint32_t)smp, P.div_n), sj = smp - si * N;
             active = j < P.cam.resx && lrow < P.local_rows;
             const int i = global_row(P, lrow);
             pixel = (uint32_t)lrow * (uint32_t)P.cam.resx + (uint32_t)j;

@@ -627,6 +627,10 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     P.part = o->part;
     P.local_rows = local_rows;
     P.blocks_x = (cam->resx + 7) / 8;
+    P.div_spp = make_fastdiv((uint32_t)(N * N));
+    P.div_blocks_x = make_fastdiv((uint32_t)P.blocks_x);
+    P.div_n = make_fastdiv((uint32_t)N);
+    P.div_band = make_fastdiv((uint32_t)band);
     P.cull_closest = may_cull ? 1 : 0;
     P.cull_shadow = (may_cull && !ctx->any_transparent_sphere) ? 1 : 0;
     // The hierarchies answer "nearest / any hit over all primitives"; that equals the reference's
@@ -717,8 +721,12 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         const long long n_chunks = blocks_y * P.blocks_x * (long long)(N * N);
         long long batch_chunks = ctx->batch_override > 0 ? (ctx->batch_override + 63) / 64
                                                           : (ctx->any_transparent ? (1ll << 22) / 64 : (1ll << 26) / 64);
+        // a batch is a whole number of 8x8-pixel blocks (N*N chunks each), so that it begins at a block, and its
+        // samples are numbered in 32 bits
+        if (batch_chunks > (1ll << 25)) batch_chunks = 1ll << 25;
+        batch_chunks = batch_chunks / (N * N) * (N * N);
         if (batch_chunks > n_chunks) batch_chunks = n_chunks;
-        if (batch_chunks < 1) batch_chunks = 1;
+        if (batch_chunks < N * N) batch_chunks = N * N;
 
         // Shard capacities, generation by generation: what one wave can be handed, times the waves
         // that feed one shard, times the fan-out of a hit (reflection, plus refraction if any
@@ -788,6 +796,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.generation = g;
                 Q.chunk_begin = t0;
                 Q.chunk_end = t1;
+                Q.block_row0 = (t0 / (N * N)) / P.blocks_x;
+                Q.block_col0 = (int32_t)((t0 / (N * N)) % P.blocks_x);
                 if (g >= 2 && P.S.n_lights > 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_s[g - 2], 0));
                 std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
                 if (timing && !(ev = next_event_pair(ctx->ev_closest, ctx->ev_closest_used)))

@@ -199,3 +199,35 @@ def test_malformed_files_are_errors_or_empty_scenes_never_a_hang(tmp_path):
     assert s.desc.n_prims == 2
     assert s.desc.n_materials == 2          # the all-zero material of the polygon that had no `f` line, then the real one
     s.close()
+
+
+def test_division_by_launch_constants():
+    """The device divides sample positions by numbers fixed per launch with a multiply-high (Granlund and
+    Montgomery's round-up method, `FastDiv` in csrc/device_records.hpp); the same arithmetic here, against //."""
+    rng = np.random.default_rng(4)
+    divisors = list(range(1, 70)) + [255, 256, 257, 960, 1000, 4095, 4096, 4097, 65535, 65536, 2 ** 20 + 7, 2 ** 28, 2 ** 31 - 1,
+                                     2 ** 31, 2 ** 31 + 1, 2 ** 32 - 1]
+    numbers = np.concatenate([np.arange(0, 300, dtype=np.uint64), rng.integers(0, 2 ** 32, 20000, dtype=np.uint64),
+                              np.array([2 ** 32 - 1, 2 ** 32 - 2, 2 ** 31, 2 ** 31 - 1], dtype=np.uint64)])
+    for d in divisors:
+        if d < 2:
+            q = numbers.copy()
+        else:
+            l = 0
+            while (1 << l) < d:
+                l += 1
+            magic = (((1 << l) - d) << 32) // d + 1
+            assert magic < 2 ** 32
+            t = (numbers * np.uint64(magic)) >> np.uint64(32)
+            q = (t + ((numbers - t) >> np.uint64(1))) >> np.uint64(l - 1)
+        assert np.array_equal(q, numbers // np.uint64(d)), d
+    for k in divisors:                          # multiples and their neighbours
+        if k >= 2:
+            n = np.array([m for m in (k, k - 1, k + 1, 3 * k, 3 * k - 1, (2 ** 32 - 1) // k * k, (2 ** 32 - 1) // k * k - 1) if 0 <= m < 2 ** 32],
+                         dtype=np.uint64)
+            l = 0
+            while (1 << l) < k:
+                l += 1
+            magic = (((1 << l) - k) << 32) // k + 1
+            t = (n * np.uint64(magic)) >> np.uint64(32)
+            assert np.array_equal((t + ((n - t) >> np.uint64(1))) >> np.uint64(l - 1), n // np.uint64(k)), k
