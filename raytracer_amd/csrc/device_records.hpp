@@ -54,7 +54,9 @@ struct DevScene {
     const int32_t *bsph_key;
     int32_t n_tri_nodes, n_sph_nodes;
     int32_t tri_cached, sph_cached;       // the first so many nodes of each hierarchy are copied into LDS by every block
+    int32_t stack_shift;                  // log2 of the block size: entry k of a thread's traversal stack is k << stack_shift words on
     int32_t lds_cache_word;               // first LDS word of the node cache (after the traversal stacks)
+    int32_t btri_cached, lds_tri_word;    // the first so many leaf triangle records (80 bytes each: what a test reads) are in LDS too, from this word on
     int32_t mat_cached, light_cached;     // the first so many materials / lights are copied into LDS as well
     int32_t lds_table_word;               // first LDS word of those tables (materials, then lights; 16 words each)
     int32_t lds_cam_word;                 // first LDS word of the camera's 16 doubles (u, v, w, e, d, l, t, pix_width)
@@ -74,6 +76,12 @@ struct DevLightCam {
     double spw;                           // sub-pixel width of the light camera (LightCam.h:223)
     double light_pos[3], sphere_pos[3];
 };
+
+// Largest block of the traversal kernels.  Large frames run one such block per compute unit (16 waves, four
+// per SIMD): the LDS copies of the top of the hierarchies, of the leaf records and of the tables then exist
+// once per compute unit instead of once per 256 threads, which leaves room for four times as much of the
+// scene.  Small frames, which live on latency and on many independent blocks, run 256-thread blocks.
+#define RT_BLOCK 1024
 
 // Division of 32-bit unsigned numbers by a divisor fixed per launch, as a multiplication (Granlund and
 // Montgomery's round-up method): for d >= 2 with l = ceil(log2 d), magic = floor(2^32 (2^l - d) / d) + 1 and

@@ -31,7 +31,7 @@ DEV void walk_count_flush(WalkCount &c, int base)
 #define WC_WAVE(cnt, field) ((void)0)
 #endif
 
-// Stack of pending nodes in LDS: entry k of a lane lives at stack[k * 256 + lane-in-block], so a
+// Stack of pending nodes in LDS: entry k of a lane lives at stack[k * block size + thread-in-block], so a
 // wave's push or pop touches 64 consecutive banks.
 #define BVH_STACK 64
 #define BVH_NONE (-1)
@@ -60,6 +60,14 @@ DEV void fill_node_cache(const DevScene &S, bool with_nodes)
             const int node = i >> 3, q = i & 7;
             const v4i v = node < S.tri_cached ? tsrc[i] : ssrc[i - S.tri_cached * 8];
             *(lds_v4i *)(lds + (S.lds_cache_word + node * NODE_LDS_WORDS + q * 4)) = v;
+        }
+    }
+    if (with_nodes) {
+        // leaf triangle records: the 80 bytes a test reads out of each 96-byte record
+        glb_v4i *src = (glb_v4i *)S.btri;
+        for (int i = (int)threadIdx.x; i < S.btri_cached * 5; i += (int)blockDim.x) {
+            const int rec = i / 5, q = i - rec * 5;
+            *(lds_v4i *)(lds + (S.lds_tri_word + i * 4)) = src[rec * 6 + q];
         }
     }
     // material and light tables (64 bytes per entry): every hit reads one of each, always the same few
@@ -97,6 +105,28 @@ DEV rt_material load_material(const DevScene &S, int index, bool lds)
 DEV rt_light load_light(const DevScene &S, int index, bool lds)
 {
     return load_entry(S.lights, index, lds ? S.light_cached : 0, S.lds_table_word + S.mat_cached * 16);
+}
+
+// Operands of the test of leaf triangle k: from LDS when the record is cached there, else from memory.
+DEV TriOps load_leaf_tri(const DevScene &S, int k)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d a, b, c, e, f;
+    if (k < S.btri_cached) {
+        const __attribute__((address_space(3))) v2d *p =
+            (const __attribute__((address_space(3))) v2d *)((__attribute__((address_space(3))) const int *)s_lds + (S.lds_tri_word + k * 20));
+        a = p[0]; b = p[1]; c = p[2]; e = p[3]; f = p[4];
+    } else {
+        const __attribute__((address_space(1))) v2d *p = (const __attribute__((address_space(1))) v2d *)&S.btri[k];
+        a = p[0]; b = p[1]; c = p[2]; e = p[3]; f = p[4];
+    }
+    TriOps t;
+    t.v0 = mk3(a.x, a.y, b.x);
+    t.ab = mk3(b.y, c.x, c.y);
+    t.ac = mk3(e.x, e.y, f.x);
+    t.prim = __double2loint(f.y);
+    t.key = __double2hiint(f.y);
+    return t;
 }
 
 // Single-precision view of a ray for the slab tests.  A child box passes when the ray's
@@ -223,7 +253,7 @@ DEV void box4_test(const accel::Bvh4Node *nodes, int cached, int lds_word, int c
 // One step down from inner node `cur`: tests its (up to) four child boxes, continues with the
 // nearest hit child and stacks the others, farthest first (or pops when nothing is hit).
 DEV int bvh4_step(const accel::Bvh4Node *nodes, int cached, int lds_word, int cur, const RayBox4 &rb, float limitf,
-                  bool ordered, int *stack, int &sp)
+                  bool ordered, int *stack, int &sp, int ss)
 {
     float kk[4];
     int cc[4];
@@ -238,29 +268,29 @@ DEV int bvh4_step(const accel::Bvh4Node *nodes, int cached, int lds_word, int cu
             if (nh) return k0 < inf ? c0 : (k1 < inf ? c1 : (k2 < inf ? c2 : c3));
             if (sp == 0) return BVH_NONE;
             --sp;
-            return stack[sp * 256];
+            return stack[sp << ss];
         }
         BVH_SORT2(k0, c0, k1, c1);
         BVH_SORT2(k2, c2, k3, c3);
         BVH_SORT2(k0, c0, k2, c2);
         BVH_SORT2(k1, c1, k3, c3);
         BVH_SORT2(k1, c1, k2, c2);
-        if (k3 < inf) { stack[sp * 256] = c3; ++sp; }
-        if (k2 < inf) { stack[sp * 256] = c2; ++sp; }
-        if (k1 < inf) { stack[sp * 256] = c1; ++sp; }
+        if (k3 < inf) { stack[sp << ss] = c3; ++sp; }
+        if (k2 < inf) { stack[sp << ss] = c2; ++sp; }
+        if (k1 < inf) { stack[sp << ss] = c1; ++sp; }
         if (k0 < inf) return c0;
     } else {
         // any order: the last hit child is kept in hand, the others go to the stack
         int next = BVH_NONE;
         if (k0 < inf) next = c0;
-        if (k1 < inf) { if (next != BVH_NONE) { stack[sp * 256] = next; ++sp; } next = c1; }
-        if (k2 < inf) { if (next != BVH_NONE) { stack[sp * 256] = next; ++sp; } next = c2; }
-        if (k3 < inf) { if (next != BVH_NONE) { stack[sp * 256] = next; ++sp; } next = c3; }
+        if (k1 < inf) { if (next != BVH_NONE) { stack[sp << ss] = next; ++sp; } next = c1; }
+        if (k2 < inf) { if (next != BVH_NONE) { stack[sp << ss] = next; ++sp; } next = c2; }
+        if (k3 < inf) { if (next != BVH_NONE) { stack[sp << ss] = next; ++sp; } next = c3; }
         if (next != BVH_NONE) return next;
     }
     if (sp == 0) return BVH_NONE;
     --sp;
-    return stack[sp * 256];
+    return stack[sp << ss];
 }
 
 struct Best {
@@ -280,6 +310,7 @@ DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb
     if ((TRI ? S.n_tri_nodes : S.n_sph_nodes) == 0) return;
     const int cached = TRI ? S.tri_cached : S.sph_cached;
     const int lds_word = S.lds_cache_word + (TRI ? 0 : S.tri_cached * NODE_LDS_WORDS);
+    const int ss = S.stack_shift;
     int cur = 0, sp = 0;
     while (true) {
         const float limitf = limit_f32(best.t * (1.0 + 1e-12) + 1e-12);
@@ -287,7 +318,7 @@ DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb
         while (cur >= 0) {
             WC_ADD(wc, lane_nodes);
             WC_WAVE(wc, wave_nodes);
-            cur = bvh4_step(nodes, cached, lds_word, cur, rb, limitf, true, stack, sp);
+            cur = bvh4_step(nodes, cached, lds_word, cur, rb, limitf, true, stack, sp, ss);
         }
         if (cur == BVH_NONE) break;
         WC_ADD(wc, lane_leaves);
@@ -297,7 +328,7 @@ DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb
             int key, prim = -1;
             WC_ADD(wc, lane_prims);
             WC_WAVE(wc, wave_prims);
-            if (TRI) { const TriOps tr = load_tri(&S.btri[k]); t = tri_test_fast(tr, o, d, minT, maxT, best.t); key = tr.key; prim = tr.prim; }
+            if (TRI) { const TriOps tr = load_leaf_tri(S, k); t = tri_test_fast(tr, o, d, minT, maxT, best.t); key = tr.key; prim = tr.prim; }
             else { t = sph_test(&S.bsph[k], o, d, d2, minT, maxT); key = S.bsph_key[k]; }
             if (t < best.t || (t == best.t && t < maxT && key < best.key)) {
                 best.t = t; best.key = key; best.slot = TRI ? k : (k | SLOT_SPHERE);
@@ -306,7 +337,7 @@ DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb
         }
         if (sp == 0) break;
         --sp;
-        cur = stack[sp * 256];
+        cur = stack[sp << ss];
     }
 }
 
@@ -320,6 +351,7 @@ DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, in
     if ((TRI ? S.n_tri_nodes : S.n_sph_nodes) == 0) return false;
     const int cached = TRI ? S.tri_cached : S.sph_cached;
     const int lds_word = S.lds_cache_word + (TRI ? 0 : S.tri_cached * NODE_LDS_WORDS);
+    const int ss = S.stack_shift;
     const float limitf = limit_f32(maxT * (1.0 + 1e-12) + 1e-12);
     int cur = 0, sp = 0;
     while (true) {
@@ -327,7 +359,7 @@ DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, in
         while (cur >= 0) {
             WC_ADD(wc, lane_nodes);
             WC_WAVE(wc, wave_nodes);
-            cur = bvh4_step(nodes, cached, lds_word, cur, rb, limitf, false, stack, sp);
+            cur = bvh4_step(nodes, cached, lds_word, cur, rb, limitf, false, stack, sp, ss);
         }
         if (cur == BVH_NONE) break;
         WC_ADD(wc, lane_leaves);
@@ -337,7 +369,7 @@ DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, in
             WC_ADD(wc, lane_prims);
             WC_WAVE(wc, wave_prims);
             if (TRI) {
-                const TriOps tr = load_tri(&S.btri[k]);
+                const TriOps tr = load_leaf_tri(S, k);
                 if (tr.prim == parent) continue;
                 t = tri_test_fast(tr, o, d, minT, maxT, maxT);
             } else {
@@ -348,7 +380,7 @@ DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, in
         }
         if (sp == 0) break;
         --sp;
-        cur = stack[sp * 256];
+        cur = stack[sp << ss];
     }
     return false;
 }

@@ -19,9 +19,9 @@
 #define RT_MIN_WAVES 1
 #endif
 template <bool PRIMARY, bool BVH>
-__global__ __launch_bounds__(256, RT_MIN_WAVES) void k_closest(FrameParams P, QueueSet Q)
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams P, QueueSet Q)
 {
-    // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
+    // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k * block size + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
     const int lane = (int)(threadIdx.x & 63);
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -249,7 +249,7 @@ template <int MODE>
 DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
 {
     constexpr bool BVH = MODE != SHADOW_EXACT;      // the hierarchies (and their LDS stacks and node cache) are in use
-    // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k*256 + thread])
+    // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k * block size + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
@@ -353,11 +353,11 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
 }
 
 template <bool BVH>
-__global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams P, QueueSet Q)
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_shadow(FrameParams P, QueueSet Q)
 {
     shadow_pass<BVH ? SHADOW_BVH : SHADOW_EXACT>(P, Q);
 }
-__global__ __launch_bounds__(256, RT_MIN_WAVES_SHADOW) void k_shadow_hybrid(FrameParams P, QueueSet Q)
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_shadow_hybrid(FrameParams P, QueueSet Q)
 {
     shadow_pass<SHADOW_HYBRID>(P, Q);
 }

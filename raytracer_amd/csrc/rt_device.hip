@@ -61,7 +61,8 @@ struct rt_ctx {
     bool any_transparent = false;          // any material with T > 0
     bool any_transparent_sphere = false;
     bool spheres_inside_root = true;       // every sphere lies inside the root cube
-    bool accel_usable = false;             // hierarchies built and shallow enough for the LDS stack
+    bool accel_usable = false;
+    long long n_btri = 0;                  // leaf triangle records of the triangle hierarchy             // hierarchies built and shallow enough for the LDS stack
     int accel_stack = 0;                   // deepest hierarchy, in nodes: the stack entries a ray can need
     // host copies needed to set up the light cameras
     std::vector<rt_light> h_lights;
@@ -160,16 +161,16 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
     HIP_TRY(hipEventCreate(&ctx->ev_end));
     HIP_TRY(hipMalloc((void **)&ctx->counts, 2 * CNT_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->totals, 16 * sizeof(unsigned long long)));
-    if (getenv("RT_DEBUG")) {
-        int n = 0;
-        for (size_t lds : {(size_t)0, (size_t)12 * 1024, (size_t)32 * 1024}) {
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_closest<true, true>, 256, lds);
-            fprintf(stderr, "[rt] k_closest<primary,bvh> lds=%zu: %d blocks/CU\n", lds, n);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shadow<true>, 256, lds);
-            fprintf(stderr, "[rt] k_shadow<bvh> lds=%zu: %d blocks/CU\n", lds, n);
-        }
-        fprintf(stderr, "[rt] CUs=%d LDS/CU=%zu sharedMemPerBlock=%zu\n", ctx->cu_count, ctx->lds_per_cu, (size_t)prop.sharedMemPerBlock);
+    {
+        // a block of the traversal kernels may use all of a compute unit's LDS
+        const int lds_max = (int)ctx->lds_per_cu;
+        const void *kernels[] = {(const void *)k_closest<true, true>,  (const void *)k_closest<true, false>, (const void *)k_closest<false, true>,
+                                 (const void *)k_closest<false, false>, (const void *)k_shadow<true>,       (const void *)k_shadow<false>,
+                                 (const void *)k_shadow_hybrid};
+        for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     }
+    if (getenv("RT_DEBUG"))
+        fprintf(stderr, "[rt] CUs=%d LDS/CU=%zu sharedMemPerBlock=%zu\n", ctx->cu_count, ctx->lds_per_cu, (size_t)prop.sharedMemPerBlock);
     *out = ctx;
     return RT_OK;
 }
@@ -311,6 +312,7 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
         D.bvh_bound = (float)(bb * 1.000001 + 1e-30);
     }
     ctx->accel_usable = acc.usable;
+    ctx->n_btri = (long long)acc.tri.size();
     ctx->accel_stack = acc.tri_bvh4.max_stack > acc.sph_bvh4.max_stack ? acc.tri_bvh4.max_stack : acc.sph_bvh4.max_stack;
     if ((rc = upload(ctx, s->sph, (size_t)s->n_sph_slots, &D.sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->sph_prim, (size_t)s->n_sph_slots, &D.sph_prim)) != RT_OK) return rc;
@@ -642,11 +644,17 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     if (stack_entries > BVH_STACK) stack_entries = BVH_STACK;
     if (stack_entries < 4) stack_entries = 4;
     // LDS per block: the stacks, the material and light tables, then as many top-of-tree nodes as fit
-    // beside them when four blocks share a compute unit (the register budget allows four waves per SIMD).
-    // A block may ask for at most 64 KiB: a tree so deep that its stacks alone do not fit keeps to the
-    // octree walk.
-    size_t lds_stack = (size_t)stack_entries * 256 * sizeof(int);
-    if (lds_stack + 8192 > 64 * 1024) bvh_closest_ok = false;
+    // beside them when the compute unit holds 1024 threads (the register budget allows four waves per SIMD).
+    // A tree so deep that its stacks alone do not fit keeps to the octree walk.
+    // Block size: see RT_BLOCK.  (The choice needs the batch size, which is fixed further down by the same rule.)
+    const long long frame_samples = (long long)n_pixels * N * N;
+    const long long batch_samples = ctx->batch_override > 0 ? ctx->batch_override : (ctx->any_transparent ? (1ll << 22) : (1ll << 26));
+    const int block = (frame_samples < batch_samples ? frame_samples : batch_samples) <= (1ll << 22) ? 256 : RT_BLOCK;
+    const int blocks_per_cu = 1024 / block, waves_per_block = block / 64;
+    P.S.stack_shift = block == 256 ? 8 : 10;
+    const size_t lds_block = ctx->lds_per_cu / blocks_per_cu;      // LDS a block may take when a compute unit is full
+    size_t lds_stack = (size_t)stack_entries * block * sizeof(int);
+    if (lds_stack + 8192 > ctx->lds_per_cu) bvh_closest_ok = false;     // (a block may take a whole compute unit's LDS)
     if (!bvh_closest_ok) lds_stack = 0;
     const bool bvh_shadow_ok = bvh_closest_ok && !ctx->any_transparent_sphere;
     // With a few transparent spheres a shadow ray is first tested against those alone: a ray that touches none
@@ -657,7 +665,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     P.S.light_cached = P.S.n_lights < 16 ? P.S.n_lights : 16;
     const size_t lds_tables = (size_t)(P.S.mat_cached + P.S.light_cached) * 64;
     {
-        const size_t per_block = ctx->lds_per_cu / 4;
+        const size_t per_block = lds_block;
         const size_t fixed = lds_stack + lds_tables + 128 + 512;
         long long room = per_block > fixed ? (long long)((per_block - fixed) / (NODE_LDS_WORDS * 4)) : 0;
         if (const char *e = std::getenv("RT_NODE_CACHE")) room = std::atoll(e) < room ? std::atoll(e) : room;   // experiments
@@ -672,12 +680,20 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         }
         P.S.tri_cached = (int32_t)nt;
         P.S.sph_cached = (int32_t)ns;
+        // what is left after the nodes takes leaf triangle records (80 bytes each)
+        long long left = (long long)(per_block > fixed ? per_block - fixed : 0) - (nt + ns) * NODE_LDS_WORDS * 4;
+        long long tc = bvh_closest_ok && left > 0 ? left / 80 : 0;
+        if (tc > ctx->n_btri) tc = ctx->n_btri;
+        if (const char *e = std::getenv("RT_TRI_CACHE")) tc = std::atoll(e) < tc ? std::atoll(e) : tc;   // experiments
+        P.S.btri_cached = (int32_t)tc;
         P.S.lds_cache_word = (int32_t)(lds_stack / sizeof(int));
-        P.S.lds_table_word = P.S.lds_cache_word + (P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS;
+        P.S.lds_tri_word = P.S.lds_cache_word + (P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS;
+        P.S.lds_table_word = P.S.lds_tri_word + P.S.btri_cached * 20;
         P.S.lds_cam_word = P.S.lds_table_word + (P.S.mat_cached + P.S.light_cached) * 16;
     }
     // every traversal kernel gets the same layout (the octree-walk variants use the tables only)
-    const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int) + lds_tables + 128;
+    const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int) +
+                           (size_t)P.S.btri_cached * 80 + lds_tables + 128;
     const size_t lds_closest = lds_bvh;
     const size_t lds_shadow = lds_bvh;
 
@@ -731,15 +747,16 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         // Shard capacities, generation by generation: what one wave can be handed, times the waves
         // that feed one shard, times the fan-out of a hit (reflection, plus refraction if any
         // material is transparent).  These are upper bounds, so a push can never overflow.
-        const int max_blocks = ctx->cu_count * 8;
+        const int max_blocks = ctx->cu_count * 2 * blocks_per_cu;     // two rounds of resident blocks
+        const int max_blocks_256 = ctx->cu_count * 8;                 // the same for kernels with 256-thread blocks
         const long long fan_out = ctx->any_transparent ? 2 : 1;
-        long long blocks0 = (batch_chunks + 3) / 4;
+        long long blocks0 = (batch_chunks + waves_per_block - 1) / waves_per_block;
         if (blocks0 > max_blocks) blocks0 = max_blocks;
-        const long long waves_q = (long long)max_blocks * 4, wps_q = ((max_blocks + N_SHARDS - 1) / N_SHARDS) * 4ll;
+        const long long waves_q = (long long)max_blocks * waves_per_block, wps_q = ((max_blocks + N_SHARDS - 1) / N_SHARDS) * (long long)waves_per_block;
         long long hit_cap[6], ray_cap[7];
         ray_cap[0] = 0;
         {
-            const long long w0 = blocks0 * 4, wps0 = ((blocks0 + N_SHARDS - 1) / N_SHARDS) * 4;
+            const long long w0 = blocks0 * waves_per_block, wps0 = ((blocks0 + N_SHARDS - 1) / N_SHARDS) * waves_per_block;
             hit_cap[0] = ((batch_chunks + w0 - 1) / w0) * 64 * wps0;
             ray_cap[1] = hit_cap[0] * fan_out;
         }
@@ -804,13 +821,13 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     return fail(RT_ERR_DEVICE, "hipEventCreate failed");
                 if (ev) HIP_TRY(hipEventRecord(ev->first, st));
                 if (g == 0) {
-                    long long blocks = (t1 - t0 + 3) / 4;
+                    long long blocks = (t1 - t0 + waves_per_block - 1) / waves_per_block;
                     if (blocks > blocks0) blocks = blocks0;
-                    if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(256), lds_closest, st, P, Q);
-                    else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(256), lds_closest, st, P, Q);
+                    if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
+                    else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                 } else {
-                    if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<false, true>), dim3((unsigned)max_blocks), dim3(256), lds_closest, st, P, Q);
-                    else hipLaunchKernelGGL((k_closest<false, false>), dim3((unsigned)max_blocks), dim3(256), lds_closest, st, P, Q);
+                    if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<false, true>), dim3((unsigned)max_blocks), dim3(block), lds_closest, st, P, Q);
+                    else hipLaunchKernelGGL((k_closest<false, false>), dim3((unsigned)max_blocks), dim3(block), lds_closest, st, P, Q);
                 }
                 if (ev) HIP_TRY(hipEventRecord(ev->second, st));
                 HIP_TRY(hipEventRecord(ctx->ev_c[g], st));
@@ -820,9 +837,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     if (timing && !(ev = next_event_pair(ctx->ev_shadow, ctx->ev_shadow_used)))
                         return fail(RT_ERR_DEVICE, "hipEventCreate failed");
                     if (ev) HIP_TRY(hipEventRecord(ev->first, sb));
-                    if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
-                    else if (hybrid_shadow) hipLaunchKernelGGL(k_shadow_hybrid, dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
-                    else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(256), lds_shadow, sb, P, Q);
+                    if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(block), lds_shadow, sb, P, Q);
+                    else if (hybrid_shadow) hipLaunchKernelGGL(k_shadow_hybrid, dim3((unsigned)max_blocks), dim3(block), lds_shadow, sb, P, Q);
+                    else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(block), lds_shadow, sb, P, Q);
                     if (ev) HIP_TRY(hipEventRecord(ev->second, sb));
                     HIP_TRY(hipEventRecord(ctx->ev_s[g], sb));
                 }
@@ -833,7 +850,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 LightcamQueues L{};
                 for (int g = 0; g < 6; ++g) { L.deferred[g] = ctx->deferred[g]; L.shard_cap[g] = (uint32_t)hit_cap[g]; }
                 L.counts = counts;
-                hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks), dim3(256), 0, sb, P, L);
+                hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks_256), dim3(256), 0, sb, P, L);
             }
             hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, sb, counts, ctx->totals, P.S.n_lights);
             HIP_TRY(hipEventRecord(ctx->ev_batch[par], sb));
@@ -846,7 +863,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         {
             const long long n_values = (long long)n_pixels * 3;
             long long blocks = (n_values + 255) / 256;
-            if (blocks > max_blocks) blocks = max_blocks;
+            if (blocks > max_blocks_256) blocks = max_blocks_256;
             hipLaunchKernelGGL(k_finalize, dim3((unsigned)blocks), dim3(256), 0, st, ctx->accum, n_values, N * N,
                                static_cast<double *>(dev[0]), static_cast<uint8_t *>(dev[1]));
             HIP_TRY(hipGetLastError());
