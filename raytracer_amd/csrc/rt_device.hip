@@ -649,7 +649,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     // Block size: see RT_BLOCK.  (The choice needs the batch size, which is fixed further down by the same rule.)
     const long long frame_samples = (long long)n_pixels * N * N;
     const long long batch_samples = ctx->batch_override > 0 ? ctx->batch_override : (ctx->any_transparent ? (1ll << 22) : (1ll << 26));
-    const int block = (frame_samples < batch_samples ? frame_samples : batch_samples) <= (1ll << 22) ? 256 : RT_BLOCK;
+    int block = (frame_samples < batch_samples ? frame_samples : batch_samples) <= (1ll << 22) ? 256 : RT_BLOCK;
+    if (const char *e = std::getenv("RT_BLOCK_THREADS")) block = std::atoi(e) == 1024 ? 1024 : 256;     // experiments
     const int blocks_per_cu = 1024 / block, waves_per_block = block / 64;
     P.S.stack_shift = block == 256 ? 8 : 10;
     const size_t lds_block = ctx->lds_per_cu / blocks_per_cu;      // LDS a block may take when a compute unit is full
@@ -775,7 +776,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         // Overlap pays when a pass cannot fill the chip by itself (small frames: each pass is one
         // ray's latency long); big batches already saturate it with one persistent grid, and there
         // the extra ordering constraints only cost, so they run on one stream.
-        const bool overlap = batch_chunks * 64 <= (1ll << 22);
+        const bool overlap = batch_chunks * 64 <= (1ll << 22) && block == 256;
         // with overlap, four hit buffers: [batch parity][generation parity], so that the shadow pass of
         // one generation (second stream) can run beside the closest-hit pass of the next one; on one
         // stream a single buffer serves every pass
