@@ -163,7 +163,6 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
         const int L = (int)(meta & 0xffu);
         const double wloc = first ? A : A * coef;
         bool hit = active && best >= 0;
-        accum_add_runs(P.accum, active, active && !hit, pixel, wloc, ld3(P.S.bg));
 
         // hit record (Solid.h:110-125)
         d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0);
@@ -177,6 +176,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
             m = load_material(P.S, mat, true);
         }
         if (PRIMARY && active && first_sample && P.hit_id) P.hit_id[pixel] = prim;
+        // misses add the background (placed after the hit's table fetches have been issued, so that their
+        // latency runs beside the shuffles and atomics of this sum)
+        accum_add_runs(P.accum, active, active && !hit, pixel, wloc, ld3(P.S.bg));
 
         // Queue pushes.  The three reservations (hit record, refraction ray, reflection ray) are made
         // with two atomics -- both kinds of ray go to the same queue -- issued back to back by one lane,
