@@ -189,6 +189,27 @@ def test_row_band_partition_reassembles(gpu, oracle_frame):
         assert (seen == 1).all()
 
 
+@pytest.mark.parametrize("scene", ["teapot-3", "balls", "gears", "refract"])
+def test_block_sizes_agree(gpu, scene):
+    """Large frames run 1024-thread blocks with one LDS copy of the scene's top per compute unit, small ones
+    256-thread blocks: the same frame through both."""
+    import os
+    s = load_scene(gpu, scene)
+    cam = s.camera(192, 160)
+    frames = []
+    for block in ("256", "1024"):
+        os.environ["RT_BLOCK_THREADS"] = block
+        try:
+            frames.append(gpu.render(cam, num_samples=2, flags=rt.FLAG_KEEP_ZERO_WEIGHT))
+        finally:
+            del os.environ["RT_BLOCK_THREADS"]
+    a, b = frames
+    assert np.array_equal(a["hit_id"], b["hit_id"])
+    assert np.array_equal(a["rgb_u8"], b["rgb_u8"])
+    assert np.abs(a["rgb_f64"] - b["rgb_f64"]).max() <= 1e-9
+    assert a["stats"]["closest_rays"] == b["stats"]["closest_rays"] and a["stats"]["shadow_rays"] == b["stats"]["shadow_rays"]
+
+
 def test_small_batches_equal_one_batch(gpu):
     s = load_scene(gpu, "refract")
     cam = s.camera(160, 160)
