@@ -231,3 +231,33 @@ def test_division_by_launch_constants():
             magic = (((1 << l) - k) << 32) // k + 1
             t = (n * np.uint64(magic)) >> np.uint64(32)
             assert np.array_equal((t + ((n - t) >> np.uint64(1))) >> np.uint64(l - 1), n // np.uint64(k)), k
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/raytracer_amd.h is the drop-in boundary: it must compile as C99 and as C++11 on its own, and a C
+    program must link against the library with nothing but the header."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc") or not shutil.which("g++"):
+        pytest.skip("no host compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "raytracer_amd.h"\n'
+                   '#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    rt_ctx *ctx = 0; rth_scene *sc = 0;\n'
+                   '    if (rth_scene_load("/nonexistent.nff", &sc) == RT_OK) return 2;\n'
+                   '    printf("%s|%d\\n", rt_last_error(), (int)sizeof(rt_node));\n'
+                   '    (void)ctx; return 0;\n'
+                   '}\n')
+    inc = os.path.join(root, "include")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "a.o")], check=True)
+    subprocess.run(["g++", "-std=c++11", "-pedantic", "-Wall", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "b.o")],
+                   check=True)
+    libdir = os.path.join(root, "raytracer_amd")
+    exe = tmp_path / "use_header"
+    subprocess.run(["gcc", str(tmp_path / "a.o"), "-o", str(exe), "-L", libdir, "-lraytracer_amd", "-Wl,-rpath," + libdir,
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip()
+    msg, size = out.rsplit("|", 1)
+    assert size == "64" and "nonexistent" in msg
