@@ -744,6 +744,12 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         batch_chunks = batch_chunks / (N * N) * (N * N);
         if (batch_chunks > n_chunks) batch_chunks = n_chunks;
         if (batch_chunks < N * N) batch_chunks = N * N;
+        if (ctx->batch_override <= 0) {
+            // equal batches instead of full ones and a short last one (a short batch costs its twelve launches all the same)
+            const long long n_batches = (n_chunks + batch_chunks - 1) / batch_chunks;
+            const long long even = (n_chunks + n_batches - 1) / n_batches;
+            batch_chunks = (even + N * N - 1) / (N * N) * (N * N);
+        }
 
         // Shard capacities, generation by generation: what one wave can be handed, times the waves
         // that feed one shard, times the fan-out of a hit (reflection, plus refraction if any
