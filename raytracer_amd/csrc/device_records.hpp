@@ -60,6 +60,7 @@ struct DevScene {
     int32_t mat_cached, light_cached;     // the first so many materials / lights are copied into LDS as well
     int32_t lds_table_word;               // first LDS word of those tables (materials, then lights; 16 words each)
     int32_t lds_cam_word;                 // first LDS word of the camera's 16 doubles (u, v, w, e, d, l, t, pix_width)
+    int32_t lds_ticket_word;              // LDS word from which the waves of a block draw their next chunk
     float bvh_bound;                      // largest |coordinate| of any hierarchy box
     // light cameras (LightCam.h): one per (transparent sphere, light) pair, index rank*n_lights+light
     const int32_t *prim_lc_rank;          // per primitive: rank among transparent spheres, or -1

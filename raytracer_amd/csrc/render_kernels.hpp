@@ -24,8 +24,6 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k * block size + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
     const int lane = (int)(threadIdx.x & 63);
-    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     ShardMap smap;
     smap.items = smap.first = smap.total = 0;
     if (!PRIMARY) smap = shard_map(&Q.counts[CNT_RAYS(Q.generation)], Q.in_shard_cap, 1u);
@@ -46,7 +44,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
     const bool cull = P.cull_closest != 0;
     WalkCount wc{};
 
-    for (long long chunk = wave; chunk < n_chunks; chunk += n_waves) {
+    for (long long chunk = next_chunk(P.S); chunk < n_chunks; chunk = next_chunk(P.S)) {
         bool active;
         d3 o, d;
         double A = 1.0, coef = 1.0;
@@ -253,8 +251,6 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
     constexpr bool BVH = MODE != SHADOW_EXACT;      // the hierarchies (and their LDS stacks and node cache) are in use
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k * block size + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
-    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     const uint32_t nl = (uint32_t)P.S.n_lights;
     // work items are (hit, light) pairs, the lights of one hit in consecutive items
     const ShardMap smap = shard_map(&Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, nl);
@@ -262,7 +258,7 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
     fill_node_cache(P.S, BVH);
     const bool cull = P.cull_shadow != 0;
     WalkCount wc{};
-    for (long long chunk = wave; chunk < (long long)smap.total; chunk += n_waves) {
+    for (long long chunk = next_chunk(P.S); chunk < (long long)smap.total; chunk = next_chunk(P.S)) {
         int shard;
         const int item = shard_locate(smap, (uint32_t)chunk, &shard);
         const bool active = item >= 0;

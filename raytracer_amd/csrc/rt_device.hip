@@ -691,10 +691,11 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         P.S.lds_tri_word = P.S.lds_cache_word + (P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS;
         P.S.lds_table_word = P.S.lds_tri_word + P.S.btri_cached * 20;
         P.S.lds_cam_word = P.S.lds_table_word + (P.S.mat_cached + P.S.light_cached) * 16;
+        P.S.lds_ticket_word = P.S.lds_cam_word + 32;
     }
     // every traversal kernel gets the same layout (the octree-walk variants use the tables only)
     const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int) +
-                           (size_t)P.S.btri_cached * 80 + lds_tables + 128;
+                           (size_t)P.S.btri_cached * 80 + lds_tables + 128 + 16;
     const size_t lds_closest = lds_bvh;
     const size_t lds_shadow = lds_bvh;
 
