@@ -17,18 +17,21 @@ struct alignas(16) RayRec {      // 80 bytes
     uint32_t _pad[2];
 };
 
-struct alignas(16) HitRec {      // 128 bytes
+struct alignas(16) HitRec {      // 128 bytes; a hit on a flat triangle writes the first 64 only (whole half lines: a store of 80 bytes
+                                 // of a line was measured slower than one of all 128)
     double P[3];                 // impactPos
-    double n[3];                 // hr.normal normalised a second time, as computeLocalColor does (Camera.h:382)
-    double nn[3];                // ... and a third time, as computeSpecularComp does (Solid.h:153)
     double v[3];                 // unit vector from the hit point to the ray origin (Solid.h:156)
     double weight;               // factor applied to the local colour
-    uint32_t pixel;
+    uint32_t pixel;              // bit 31 (HIT_FLAT): a triangle shaded with its own normal -- n and nn are the primitive's entry of
+                                 // prim_n23 and its material comes from prim_material; nothing beyond this word is stored
     int32_t prim;                // the solid that was hit (never occludes itself)
     int32_t light, cam;          // only in the deferred light-camera queue: light index, camera index
     int32_t mat;                 // material index of `prim`
     int32_t _pad;
+    double n[3];                 // hr.normal normalised a second time, as computeLocalColor does (Camera.h:382)
+    double nn[3];                // ... and a third time, as computeSpecularComp does (Solid.h:153)
 };
+#define HIT_FLAT 0x80000000u
 static_assert(sizeof(HitRec) == 128, "HitRec must be 128 bytes");
 
 struct DevScene {
@@ -41,6 +44,7 @@ struct DevScene {
     const double *prim_normals;
     const double *prim_units;             // per primitive 9 doubles: the flat normal normalised once, twice and three times more
                                           // (Solid.h:119, Camera.h:382, Solid.h:153), constants of a flat triangle; zeros for spheres
+    const double *prim_n23;               // per primitive 6 doubles: the last two of those (what the shading of a flat triangle reads)
     const rt_material *materials;
     const rt_light *lights;
     int32_t n_nodes, n_lights;

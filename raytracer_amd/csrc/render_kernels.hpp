@@ -205,15 +205,18 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
             Q.counts[CNT_OVERFLOW] = 1u;
 
         if (want_hit && slot_h < Q.hit_shard_cap) {
-            d3 n2, n3;
-            if (flat) { const double *u = &P.S.prim_units[(size_t)prim * 9]; n2 = ld3(u + 3); n3 = ld3(u + 6); }
-            else { n2 = unit3(n); n3 = unit3(n2); }
             const d3 vv = unit3(sub3(o, Pt));
-            // HitRec: P, n, nn, v, weight, pixel, prim, light, cam, mat, pad
-            const rec_v2d q[8] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, n2.x), rec_pack(n2.y, n2.z), rec_pack(n3.x, n3.y),
-                                  rec_pack(n3.z, vv.x), rec_pack(vv.y, vv.z),
-                                  rec_pack(wloc, __hiloint2double(prim, (int)pixel)), rec_pack_words(0u, 0u, (uint32_t)mat, 0u)};
-            rec_store(&Q.hits[(size_t)shard * Q.hit_shard_cap + slot_h], q);
+            HitRec *dst = &Q.hits[(size_t)shard * Q.hit_shard_cap + slot_h];
+            // HitRec: P, v, weight, pixel, prim -- and for a hit whose normal is not its primitive's tabulated one
+            // (a sphere, interpolated vertex normals) the material and the normal normalised twice and thrice
+            const rec_v2d q[4] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, vv.x), rec_pack(vv.y, vv.z),
+                                  rec_pack(wloc, __hiloint2double(prim, (int)(pixel | (flat ? HIT_FLAT : 0u))))};
+            rec_store(dst, q);
+            if (!flat) {
+                const d3 n2 = unit3(n), n3 = unit3(n2);
+                const rec_v2d r[4] = {rec_pack_words(0u, 0u, (uint32_t)mat, 0u), rec_pack(n2.x, n2.y), rec_pack(n2.z, n3.x), rec_pack(n3.y, n3.z)};
+                rec_store(&dst->light, r);
+            }
         }
         if (want_refr && slot_a < Q.out_shard_cap) {
             const d3 rd = refract_dir(d, n, m.ior, false);
@@ -266,12 +269,13 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
         const int li = active ? (int)((uint32_t)item - h * nl) : 0;
         const HitRec *hr = &Q.hits[(size_t)shard * Q.hit_shard_cap + h];
         // head of the record: P, weight, pixel, prim, material -- four 16-byte pieces fetched together
-        const rec_v2d h0 = rec_load(hr, 0), h1 = rec_load(hr, 1), h6 = rec_load(hr, 6), h7 = rec_load(hr, 7);
+        const rec_v2d h0 = rec_load(hr, 0), h1 = rec_load(hr, 1), h3 = rec_load(hr, 3);
         const d3 Pt = mk3(h0.x, h0.y, h1.x);
-        const double weight = h6.x;
-        const int hit_prim = __double2hiint(h6.y), hit_mat = __double2loint(h7.y);
+        const double weight = h3.x;
+        const int hit_prim = __double2hiint(h3.y);
+        const bool hit_flat = ((uint32_t)__double2loint(h3.y) & HIT_FLAT) != 0;
         const d3 lpos = ld3(load_light(P.S, li, true).pos);
-        const uint32_t pixel = (uint32_t)__double2loint(h6.y);
+        const uint32_t pixel = (uint32_t)__double2loint(h3.y) & ~HIT_FLAT;
         bool lit = false;
         int defer_cam = -1;
         d3 local = mk3(0, 0, 0);
@@ -318,10 +322,13 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
             lit = !occluded;
             if (lit) {
                 const rt_light lgt = load_light(P.S, li, true);     // read again here rather than kept in registers through the walk
-                // the rest of the record (n, nn, v) in five pieces, also together
-                const rec_v2d g1 = rec_load(hr, 1), g2 = rec_load(hr, 2), g3 = rec_load(hr, 3), g4 = rec_load(hr, 4), g5 = rec_load(hr, 5);
-                local = phong_terms(load_material(P.S, hit_mat, true), mk3(g1.y, g2.x, g2.y), mk3(g3.x, g3.y, g4.x),
-                                    mk3(g4.y, g5.x, g5.y), &lgt, rd, .999999);
+                // the view vector from the record; the two normals from the record too, or from the primitive's table
+                // entry when they are the flat triangle's own -- four 16-byte pieces fetched together
+                const void *nsrc = hit_flat ? (const void *)&P.S.prim_n23[(size_t)hit_prim * 6] : (const void *)hr->n;
+                const rec_v2d g2 = rec_load(hr, 2), n0 = rec_load(nsrc, 0), n1 = rec_load(nsrc, 1), n2 = rec_load(nsrc, 2);
+                const int hit_mat = hit_flat ? P.S.prim_material[hit_prim] : hr->mat;
+                local = phong_terms(load_material(P.S, hit_mat, true), mk3(n0.x, n0.y, n1.x), mk3(n1.y, n2.x, n2.y),
+                                    mk3(h1.y, g2.x, g2.y), &lgt, rd, .999999);
             }
         }
         if (MODE != SHADOW_BVH && P.S.lc_table) {
@@ -331,14 +338,18 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
             if (ok) {
                 HitRec *dr = &Q.deferred[slot];
                 *dr = *hr;
+                dr->pixel = pixel | (hit_flat ? HIT_FLAT : 0u);
                 dr->light = li;
                 dr->cam = defer_cam;
+                if (hit_flat) dr->mat = P.S.prim_material[hit_prim];
             } else if (want) {   // queue full: evaluate here
                 const double kfac = lc_calc_intensity(P.S.lc_table, defer_cam, Pt);
                 if (kfac > .01) {
                     lit = true;
                     const rt_light lgt = load_light(P.S, li, true);
-                    local = phong_terms(load_material(P.S, hit_mat, true), ld3(hr->n), ld3(hr->nn), ld3(hr->v), &lgt,
+                    const double *nsrc = hit_flat ? &P.S.prim_n23[(size_t)hit_prim * 6] : hr->n;
+                    const int hit_mat = hit_flat ? P.S.prim_material[hit_prim] : hr->mat;
+                    local = phong_terms(load_material(P.S, hit_mat, true), ld3(nsrc), ld3(nsrc + 3), ld3(hr->v), &lgt,
                                         unit3(sub3(lpos, Pt)), kfac);
                 }
             }
@@ -404,11 +415,12 @@ __global__ __launch_bounds__(256) void k_lightcam(FrameParams P, LightcamQueues 
             const rt_light *lt = &P.S.lights[hr->light];
             if (kfac > .01) {
                 lit = true;
-                local = phong_terms(load_material(P.S, hr->mat, false), ld3(hr->n), ld3(hr->nn), ld3(hr->v), lt,
+                const double *nsrc = (hr->pixel & HIT_FLAT) ? &P.S.prim_n23[(size_t)hr->prim * 6] : hr->n;
+                local = phong_terms(load_material(P.S, hr->mat, false), ld3(nsrc), ld3(nsrc + 3), ld3(hr->v), lt,
                                     unit3(sub3(ld3(lt->pos), Pt)), kfac);
             }
         }
-        accum_add_runs(P.accum, active, lit, hr->pixel, hr->weight, local);
+        accum_add_runs(P.accum, active, lit, hr->pixel & ~HIT_FLAT, hr->weight, local);
     }
 }
 

@@ -332,6 +332,10 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
             }
         }
         if ((rc = upload(ctx, units.data(), units.size(), &D.prim_units)) != RT_OK) return rc;
+        std::vector<double> n23((size_t)s->n_prims * 6);
+        for (int32_t p = 0; p < s->n_prims; ++p)
+            for (int k = 0; k < 6; ++k) n23[(size_t)p * 6 + k] = units[(size_t)p * 9 + 3 + k];
+        if ((rc = upload(ctx, n23.data(), n23.size(), &D.prim_n23)) != RT_OK) return rc;
     }
     if ((rc = upload(ctx, s->materials, (size_t)s->n_materials, &D.materials)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->lights, (size_t)s->n_lights, &D.lights)) != RT_OK) return rc;
