@@ -137,6 +137,7 @@ struct QueueSet {
     HitRec *deferred;            // light-camera evaluations postponed by the shadow pass (same shard size as hits)
     uint32_t *counts;
     uint32_t in_shard_cap, out_shard_cap, hit_shard_cap;   // records per shard
+    uint32_t hit_stride;         // bytes from one hit record to the next: 128, or 64 when every hit of the scene is a flat triangle's
     int32_t generation;
     int64_t chunk_begin, chunk_end;  // PRIMARY only: 64-sample chunks of the primary ordering; a batch begins at a
                                      // block of 8x8 pixels (chunk_begin is a multiple of N*N)

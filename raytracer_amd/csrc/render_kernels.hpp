@@ -206,7 +206,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
 
         if (want_hit && slot_h < Q.hit_shard_cap) {
             const d3 vv = unit3(sub3(o, Pt));
-            HitRec *dst = &Q.hits[(size_t)shard * Q.hit_shard_cap + slot_h];
+            HitRec *dst = (HitRec *)((char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + slot_h) * Q.hit_stride);
             // HitRec: P, v, weight, pixel, prim -- and for a hit whose normal is not its primitive's tabulated one
             // (a sphere, interpolated vertex normals) the material and the normal normalised twice and thrice
             const rec_v2d q[4] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, vv.x), rec_pack(vv.y, vv.z),
@@ -267,7 +267,7 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
         const bool active = item >= 0;
         const uint32_t h = active ? (uint32_t)item / nl : 0u;
         const int li = active ? (int)((uint32_t)item - h * nl) : 0;
-        const HitRec *hr = &Q.hits[(size_t)shard * Q.hit_shard_cap + h];
+        const HitRec *hr = (const HitRec *)((const char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + h) * Q.hit_stride);
         // head of the record: P, weight, pixel, prim, material -- four 16-byte pieces fetched together
         const rec_v2d h0 = rec_load(hr, 0), h1 = rec_load(hr, 1), h3 = rec_load(hr, 3);
         const d3 Pt = mk3(h0.x, h0.y, h1.x);

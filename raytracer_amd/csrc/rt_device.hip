@@ -60,6 +60,7 @@ struct rt_ctx {
     bool has_scene = false;
     bool any_transparent = false;          // any material with T > 0
     bool any_transparent_sphere = false;
+    bool any_sphere = false, any_vnormals = false;
     bool spheres_inside_root = true;       // every sphere lies inside the root cube
     bool accel_usable = false;
     long long n_btri = 0;                  // leaf triangle records of the triangle hierarchy             // hierarchies built and shallow enough for the LDS stack
@@ -372,6 +373,9 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     ctx->n_materials = s->n_materials;
     ctx->any_transparent = false;
     for (int32_t i = 0; i < s->n_materials; ++i) if (s->materials[i].T > 0) ctx->any_transparent = true;
+    ctx->any_sphere = s->n_sph_slots > 0;
+    ctx->any_vnormals = false;
+    for (int32_t p = 0; p < s->n_prims; ++p) if (s->prim_flags[p] & RT_PRIM_HAS_VNORMALS) ctx->any_vnormals = true;
     ctx->any_transparent_sphere = false;
     for (int32_t i = 0; i < s->n_sph_slots; ++i) if (s->sph_prim[i] & RT_SPH_TRANSPARENT) ctx->any_transparent_sphere = true;
     // Pruning by entry distance is only result-preserving when every sphere surface point
@@ -662,6 +666,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     if (lds_stack + 8192 > ctx->lds_per_cu) bvh_closest_ok = false;     // (a block may take a whole compute unit's LDS)
     if (!bvh_closest_ok) lds_stack = 0;
     const bool bvh_shadow_ok = bvh_closest_ok && !ctx->any_transparent_sphere;
+    // every hit record is the 64-byte kind when the scene has no sphere and no triangle is shaded with
+    // interpolated normals; the records then lie back to back
+    const bool all_flat = !ctx->any_sphere && !((o->flags & RT_FLAG_PHONG_NORMALS) && ctx->any_vnormals);
     // With a few transparent spheres a shadow ray is first tested against those alone: a ray that touches none
     // of them has an order-free answer and takes the hierarchies; only the others walk the octree.
     const bool hybrid_shadow = bvh_closest_ok && ctx->any_transparent_sphere && P.S.n_tsph <= MAX_HYBRID_SPHERES &&
@@ -822,6 +829,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.in_shard_cap = (uint32_t)ray_cap[g];
                 Q.out_shard_cap = (uint32_t)(g < 5 ? ray_cap[g + 1] : 0);
                 Q.hit_shard_cap = (uint32_t)hit_cap[g];
+                Q.hit_stride = all_flat ? 64u : 128u;
                 Q.generation = g;
                 Q.chunk_begin = t0;
                 Q.chunk_end = t1;
