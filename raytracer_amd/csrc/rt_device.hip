@@ -656,7 +656,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     // A tree so deep that its stacks alone do not fit keeps to the octree walk.
     // Block size: see RT_BLOCK.  (The choice needs the batch size, which is fixed further down by the same rule.)
     const long long frame_samples = (long long)n_pixels * N * N;
-    const long long batch_samples = ctx->batch_override > 0 ? ctx->batch_override : (ctx->any_transparent ? (1ll << 22) : (1ll << 26));
+    const long long batch_samples = ctx->batch_override > 0 ? ctx->batch_override : (ctx->any_transparent ? (1ll << 22) : (1ll << 28));
     int block = (frame_samples < batch_samples ? frame_samples : batch_samples) <= (1ll << 22) ? 256 : RT_BLOCK;
     if (const char *e = std::getenv("RT_BLOCK_THREADS")) block = std::atoi(e) == 1024 ? 1024 : 256;     // experiments
     const int blocks_per_cu = 1024 / block, waves_per_block = block / 64;
@@ -749,7 +749,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         const long long blocks_y = ((long long)local_rows + 7) / 8;
         const long long n_chunks = blocks_y * P.blocks_x * (long long)(N * N);
         long long batch_chunks = ctx->batch_override > 0 ? (ctx->batch_override + 63) / 64
-                                                          : (ctx->any_transparent ? (1ll << 22) / 64 : (1ll << 26) / 64);
+                                                          : (ctx->any_transparent ? (1ll << 22) / 64 : (1ll << 28) / 64);
         // a batch is a whole number of 8x8-pixel blocks (N*N chunks each), so that it begins at a block, and its
         // samples are numbered in 32 bits
         if (batch_chunks > (1ll << 25)) batch_chunks = 1ll << 25;
