@@ -252,6 +252,9 @@ template <int MODE>
 DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
 {
     constexpr bool BVH = MODE != SHADOW_EXACT;      // the hierarchies (and their LDS stacks and node cache) are in use
+#ifdef RT_COUNT
+    const long long t_begin = wall_clock64();
+#endif
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k * block size + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
     const uint32_t nl = (uint32_t)P.S.n_lights;
@@ -358,6 +361,9 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
     }
 #ifdef RT_COUNT
     walk_count_flush(wc, 16);
+    // lifetime of the wave in 100 MHz ticks: summed over a launch and set against its duration it tells how full
+    // the resident wave slots were (tools/exp_tail.py)
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_walk_counts[40], (unsigned long long)(wall_clock64() - t_begin));
 #endif
 }
 

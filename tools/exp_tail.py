@@ -1,5 +1,7 @@
+"""How full the resident wave slots are over the shadow launches of the 8K x 16 spp frame (-DRT_COUNT build).
+usage: RAYTRACER_AMD_LIB=build_variants/lib_count.so python tools/exp_tail.py"""
 import ctypes as C, os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 lib = rt.load()
 fn = C.CDLL(rt.LIB_PATH).rt_debug_counters
