@@ -766,7 +766,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         // Shard capacities, generation by generation: what one wave can be handed, times the waves
         // that feed one shard, times the fan-out of a hit (reflection, plus refraction if any
         // material is transparent).  These are upper bounds, so a push can never overflow.
-        const int max_blocks = ctx->cu_count * 2 * blocks_per_cu;     // two rounds of resident blocks
+        int rounds = 2;
+        if (const char *e = std::getenv("RT_ROUNDS")) rounds = std::atoi(e) > 0 ? std::atoi(e) : 2;      // experiments
+        const int max_blocks = ctx->cu_count * rounds * blocks_per_cu;     // so many rounds of resident blocks
         const int max_blocks_256 = ctx->cu_count * 8;                 // the same for kernels with 256-thread blocks
         const long long fan_out = ctx->any_transparent ? 2 : 1;
         long long blocks0 = (batch_chunks + waves_per_block - 1) / waves_per_block;
