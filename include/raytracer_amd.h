@@ -37,7 +37,7 @@ enum {
     RT_ERR_INVALID = -1,      /* bad argument or inconsistent scene arrays */
     RT_ERR_DEVICE = -2,       /* HIP runtime error, or no MI355X-class device */
     RT_ERR_IO = -3,           /* file could not be opened / parsed */
-    RT_ERR_CAPACITY = -4,     /* a ray queue overflowed (never expected; see rt_render) */
+    RT_ERR_CAPACITY = -4,     /* a ray queue overflowed (rt_sync), or a request exceeds a fixed capacity */
     RT_ERR_UNSUPPORTED = -5
 };
 
@@ -179,6 +179,19 @@ int rt_render_async(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *opt
 int rt_sync(rt_ctx *ctx, rt_stats *stats);
 /* Primary batch size (primary samples per pipeline pass); 0 restores the default. */
 int rt_set_batch(rt_ctx *ctx, int64_t primaries);
+/* Device memory the ray/hit queues of this context may take (bytes; 0 restores the default).  A frame whose
+ * batch would need more runs in smaller batches; results do not depend on it. */
+int rt_set_memory_budget(rt_ctx *ctx, size_t bytes);
+
+/* Queue depth.  The queues of a batch hold, per generation of the ray tree, a fixed multiple of the batch's primary
+ * samples (2 at first) instead of the 32-fold worst case of a scene in which every hit both reflects and refracts.
+ * If a frame outgrows them, rt_sync returns RT_ERR_CAPACITY (the outputs are incomplete) and the context doubles
+ * the multiple for its next frame; rt_render does that re-rendering by itself and only returns a complete frame. */
+
+/* Diagnostic: experiment switches of one context, none of which changes a result.  Names: "block_threads" (256 or
+ * 1024, 0 = per-frame choice), "node_cache", "tri_cache" (caps on what is copied into LDS, -1 = none), "rounds",
+ * "verbose", "queue_growth" (1..32), and for the next rt_upload_scene "leaf_max" (1..4), "split_budget" (percent). */
+int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value);
 
 /* Diagnostic: runs the kernels' own primitive tests on n (primitive, ray) pairs, one per GPU thread, so that
  * each can be compared with the reference's function in isolation.

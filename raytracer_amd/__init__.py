@@ -118,6 +118,8 @@ _SIGNATURES = {
     "rt_render_async": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.POINTER(FrameOut)]),
     "rt_sync": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rt_set_batch": (C.c_int, [C.c_void_p, C.c_int64]),
+    "rt_set_memory_budget": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rt_debug_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "rt_debug_intersect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.c_double, C.c_double, C.POINTER(C.c_double)]),
     "rth_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -314,6 +316,13 @@ class Renderer:
 
     def set_batch(self, primaries):
         _check(load().rt_set_batch(self._ctx, primaries))
+
+    def set_memory_budget(self, nbytes):
+        _check(load().rt_set_memory_budget(self._ctx, nbytes))
+
+    def set_option(self, name, value):
+        """Experiment switch of this context (rt_debug_set_option)."""
+        _check(load().rt_debug_set_option(self._ctx, name.encode(), int(value)))
 
     @staticmethod
     def _opts(num_samples, aperture, flags, seed, band_rows, n_parts, part):

@@ -301,7 +301,7 @@ double item_area(const Item &it)
 // Cuts, most profitable first, until the items have grown by `budget_percent` or no cut saves at
 // least `kMinSaving` of a box; the result replaces `items` only if it pays for the scene as a whole.  (A cut that saves less -- an axis-aligned right triangle saves a
 // quarter -- makes the tree larger for little.)
-void split_references(std::vector<Item> &items, const rt_tri_rec *records, int budget_percent)
+void split_references(std::vector<Item> &items, const rt_tri_rec *records, int budget_percent, bool verbose)
 {
     constexpr double kMinSaving = 0.3, kMinTotalSaving = 0.25;
     const size_t budget = items.size() * static_cast<size_t>(budget_percent) / 100;
@@ -367,7 +367,7 @@ void split_references(std::vector<Item> &items, const rt_tri_rec *records, int b
     for (const Item &it : items) before += item_area(it);
     for (const Item &it : done) after += item_area(it);
     const bool keep = after <= (1 - kMinTotalSaving) * before;
-    if (std::getenv("RT_DEBUG"))
+    if (verbose)
         std::fprintf(stderr, "[rt] reference splitting: %zu -> %zu items, box area %.4g -> %.4g (%.1f %% saved): %s\n", items.size(),
                      done.size(), before, after, before > 0 ? 100 * (before - after) / before : 0.0, keep ? "kept" : "dropped");
     if (keep) items.swap(done);
@@ -509,14 +509,11 @@ void collapse(const Bvh &b2, Bvh4 &out)
 
 }  // namespace
 
-void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_tri, std::vector<int32_t> &octree_sph_key)
+void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_tri, std::vector<int32_t> &octree_sph_key,
+           const Options &opt)
 {
     out = Accel();
-    int leaf_max = kLeafMaxDefault;
-    if (const char *e = std::getenv("RT_LEAF_MAX")) {      // experiments only
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 4) leaf_max = v;
-    }
+    const int leaf_max = (opt.leaf_max >= 1 && opt.leaf_max <= 4) ? opt.leaf_max : kLeafMaxDefault;
     octree_tri.assign(d.tri, d.tri + d.n_tri_slots);
     octree_sph_key.assign(static_cast<size_t>(d.n_sph_slots), 0);
 
@@ -572,9 +569,8 @@ void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_t
         for (const Item &it : *items)
             for (int k = 0; k < 3; ++k)
                 if (!(std::fabs(it.lo[k]) < 1e6) || !(std::fabs(it.hi[k]) < 1e6)) return;   // usable stays false
-    int split_budget = kSplitBudgetPercent;
-    if (const char *e = std::getenv("RT_SPLIT_BUDGET")) split_budget = std::max(0, std::atoi(e));      // experiments only
-    split_references(tri_items, d.tri, split_budget);
+    const int split_budget = opt.split_budget >= 0 ? opt.split_budget : kSplitBudgetPercent;
+    split_references(tri_items, d.tri, split_budget, opt.verbose);
     Builder(tri_items, out.tri_bvh, leaf_max).run();
     Builder(sph_items, out.sph_bvh, leaf_max).run();
     out.tri.reserve(tri_items.size());

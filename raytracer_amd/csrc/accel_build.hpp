@@ -58,9 +58,16 @@ struct Accel {
     bool usable = false;                // false: keep to the octree walk
 };
 
+// Experiment knobs of the builder; the defaults are what the product uses.
+struct Options {
+    int leaf_max = 0;        // primitives per leaf, 1..4; 0 = default (2)
+    int split_budget = -1;   // growth in percent allowed to reference splitting; < 0 = default (100), 0 = off
+    bool verbose = false;    // splitter statistics on stderr
+};
+
 // Also fills the per-slot helper fields of `octree_tri` (copy of desc.tri): key and the
 // ray-independent minor.  `octree_sph_key` receives one key per octree sphere slot.
 void build(const rt_scene_desc &desc, Accel &out, std::vector<rt_tri_rec> &octree_tri,
-           std::vector<int32_t> &octree_sph_key);
+           std::vector<int32_t> &octree_sph_key, const Options &opt = Options());
 
 }  // namespace accel

@@ -49,6 +49,19 @@ extern "C" const char *rt_last_error(void) { return g_error.c_str(); }
             return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
     } while (0)
 
+// Queue memory one context may take unless rt_set_memory_budget says otherwise.
+#define RT_DEFAULT_QUEUE_BUDGET ((size_t)96 << 30)
+
+// Experiment switches (rt_debug_set_option); the defaults are what the product runs.
+struct DebugOptions {
+    int block_threads = 0;          // 256 or 1024 overrides the per-frame choice
+    long long node_cache = -1;      // cap on hierarchy nodes copied into LDS
+    long long tri_cache = -1;       // cap on leaf triangle records copied into LDS
+    int rounds = 0;                 // rounds of resident blocks a queued pass is cut into (default 2)
+    bool verbose = false;           // device properties, light-camera and splitter statistics on stderr
+    int leaf_max = 0, split_budget = -1;   // hierarchy builder (accel::Options), read at the next upload
+};
+
 // ------------------------------------------------------------------ host side
 struct rt_ctx {
     int device = 0;
@@ -84,7 +97,11 @@ struct rt_ctx {
     unsigned long long *totals = nullptr;
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr}; size_t stage_bytes[4] = {0, 0, 0, 0};
     int64_t batch_override = 0;
+    size_t queue_budget = RT_DEFAULT_QUEUE_BUDGET;
+    int growth = 2;                        // ray queues hold this many times the first generation's capacity (plan_queues)
+    DebugOptions dbg;
     // pending async frame
+    unsigned long long *pending_totals = nullptr;
     bool pending = false;
     uint32_t pending_flags = 0;
     unsigned long long pending_primaries = 0;
@@ -170,8 +187,6 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
                                  (const void *)k_shadow_hybrid};
         for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     }
-    if (getenv("RT_DEBUG"))
-        fprintf(stderr, "[rt] CUs=%d LDS/CU=%zu sharedMemPerBlock=%zu\n", ctx->cu_count, ctx->lds_per_cu, (size_t)prop.sharedMemPerBlock);
     *out = ctx;
     return RT_OK;
 }
@@ -297,7 +312,11 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     accel::Accel acc;
     std::vector<rt_tri_rec> octree_tri;
     std::vector<int32_t> octree_sph_key;
-    accel::build(*s, acc, octree_tri, octree_sph_key);
+    accel::Options aopt;
+    aopt.leaf_max = ctx->dbg.leaf_max;
+    aopt.split_budget = ctx->dbg.split_budget;
+    aopt.verbose = ctx->dbg.verbose;
+    accel::build(*s, acc, octree_tri, octree_sph_key, aopt);
     if ((rc = upload(ctx, octree_tri.data(), octree_tri.size(), &D.tri)) != RT_OK) return rc;
     if ((rc = upload(ctx, acc.tri_bvh4.nodes.data(), acc.tri_bvh4.nodes.size(), &D.tri_nodes)) != RT_OK) return rc;
     if ((rc = upload(ctx, acc.sph_bvh4.nodes.data(), acc.sph_bvh4.nodes.size(), &D.sph_nodes)) != RT_OK) return rc;
@@ -388,6 +407,7 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
             double c = s->sph[i].center[k] - root.center[k];
             if (!(std::fabs(c) + s->sph[i].radius < half * (1.0 - 1e-9))) ctx->spheres_inside_root = false;
         }
+    ctx->growth = 2;
     ctx->has_scene = true;
     return RT_OK;
 }
@@ -416,6 +436,8 @@ extern "C" int rt_part_rows(const rt_camera *cam, const rt_render_opts *opts, in
     return RT_OK;
 }
 
+// Grow-only device buffer.  A failed allocation leaves the buffer empty and reports RT_ERR_DEVICE; the caller
+// may try again with a smaller request.
 template <typename T>
 static int ensure(T **ptr, size_t *have, size_t want)
 {
@@ -423,7 +445,12 @@ static int ensure(T **ptr, size_t *have, size_t want)
     if (*ptr) HIP_TRY(hipFree(*ptr));
     *ptr = nullptr;
     *have = 0;
-    HIP_TRY(hipMalloc((void **)ptr, sizeof(T) * want));
+    hipError_t e = hipMalloc((void **)ptr, sizeof(T) * want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        return fail(RT_ERR_DEVICE, std::string("hipMalloc of ") + std::to_string(sizeof(T) * want) + " bytes: " + hipGetErrorString(e));
+    }
     *have = want;
     return RT_OK;
 }
@@ -444,21 +471,27 @@ static std::pair<hipEvent_t, hipEvent_t> *next_event_pair(std::vector<std::pair<
 // only on its pair, so building all of them ahead changes no pixel.
 // All cameras are built ahead, so their number is bounded: by LC_MAX_PAIRS, and by memory -- a light
 // ray leaves about three weighted points, and a point costs about 64 bytes with its share of the tree;
-// the cameras may take a quarter of the free device memory.  Beyond either bound the term stays off and
-// the affected pixels are only marked in the light-camera mask.
+// the cameras may take a quarter of the free device memory.  Beyond either bound the call fails with
+// RT_ERR_CAPACITY (a frame without the term would differ from the reference's); RT_FLAG_NO_LIGHTCAM
+// renders such a scene without it on request.
 #define LC_MAX_PAIRS 4096
 static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
 {
     free_lightcams(ctx);
     const size_t n_pairs = ctx->h_lc_spheres.size() * ctx->h_lights.size();
-    if (n_pairs == 0 || n_pairs > LC_MAX_PAIRS) return RT_OK;
+    if (n_pairs == 0) return RT_OK;
+    if (n_pairs > LC_MAX_PAIRS)
+        return fail(RT_ERR_CAPACITY, "rt_render: " + std::to_string(n_pairs) + " (transparent sphere, light) pairs, more than the " +
+                                         std::to_string(LC_MAX_PAIRS) + " light cameras this build sets up; RT_FLAG_NO_LIGHTCAM renders without the term");
     const int N = ctx->lightcam_samples;
     if (N < 1 || N > 4096) return fail(RT_ERR_INVALID, "light camera sample count (Z) must be in 1..4096");
     const size_t n_rays = (size_t)N * N;
     {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if ((double)n_pairs * (double)n_rays * 3.0 * 64.0 > 0.25 * (double)free_b) return RT_OK;
+        if ((double)n_pairs * (double)n_rays * 3.0 * 64.0 > 0.25 * (double)free_b)
+            return fail(RT_ERR_CAPACITY, "rt_render: the light cameras of this scene would need more than a quarter of the free device "
+                                         "memory; RT_FLAG_NO_LIGHTCAM renders without the term");
     }
     lightcam::Point *d_slots = nullptr;
     int32_t *d_counts = nullptr;
@@ -584,7 +617,7 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
     (void)hipFree(d_slots);
     (void)hipFree(d_counts);
     (void)hipFree(d_offsets);
-    if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rt] %zu light-camera trees: %.1f ms waiting for the host threads after the photon passes\n", n_pairs, build_ms);
+    if (ctx->dbg.verbose) fprintf(stderr, "[rt] %zu light-camera trees: %.1f ms waiting for the host threads after the photon passes\n", n_pairs, build_ms);
     if (rc != RT_OK) { free_lightcams(ctx); return rc; }
     void *dt = nullptr;
     HIP_TRY(hipMalloc(&dt, sizeof(DevLightCam) * n_pairs));
@@ -596,8 +629,118 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
     return RT_OK;
 }
 
-static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *o, const rt_frame_out *out,
-                         bool outputs_on_device)
+// ------------------------------------------------------------------ frame planning
+// Sizes of the sharded queues of one batch.  A block pushes into shard blockIdx % N_SHARDS and the 64-item chunks
+// of a pass are dealt to the blocks in a fixed pattern, so what a shard can receive in a generation follows from
+// what one wave can be handed, times the waves that feed the shard: with those capacities a push cannot overflow
+// as long as the generation's input fits its own queue.  The input of generation g+1 is at most fan_out times the
+// hits of generation g (reflection, plus refraction when a material is transparent).  Carried through six
+// generations that bound is 32 times the primary count, which no real scene approaches (the reference's scenes
+// stay below 1.3 rays per primary in every generation), so the ray queues are capped at `growth` times the
+// first generation's capacity.  A push beyond a capacity is dropped and raises the overflow word; rt_sync reports
+// it (RT_ERR_CAPACITY), the context doubles `growth`, and rt_render renders the frame again by itself.
+struct QueuePlan {
+    long long batch_chunks = 0;
+    int max_blocks = 0;               // grid of the queued passes
+    long long blocks0 = 0;            // grid of a full primary pass
+    long long hit_cap[6] = {}, ray_cap[7] = {};      // records per shard
+    long long need_rays[2] = {0, 0}, need_hits = 0;  // records per buffer
+    int hit_buffers = 1;
+    bool deferred = false;
+    size_t bytes() const
+    {
+        size_t b = (size_t)(need_rays[0] + need_rays[1]) * sizeof(RayRec) + (size_t)need_hits * sizeof(HitRec) * hit_buffers;
+        if (deferred)
+            for (int g = 0; g < 6; ++g) b += (size_t)(hit_cap[g] * N_SHARDS) * sizeof(HitRec);
+        return b;
+    }
+};
+
+static void plan_queues(QueuePlan &q, long long batch_chunks, int waves_per_block, int max_blocks, long long fan_out, long long growth)
+{
+    q.batch_chunks = batch_chunks;
+    q.max_blocks = max_blocks;
+    long long blocks0 = (batch_chunks + waves_per_block - 1) / waves_per_block;
+    if (blocks0 > max_blocks) blocks0 = max_blocks;
+    q.blocks0 = blocks0;
+    const long long waves_q = (long long)max_blocks * waves_per_block;
+    const long long wps_q = ((max_blocks + N_SHARDS - 1) / N_SHARDS) * (long long)waves_per_block;
+    const long long w0 = blocks0 * waves_per_block, wps0 = ((blocks0 + N_SHARDS - 1) / N_SHARDS) * waves_per_block;
+    q.ray_cap[0] = 0;
+    q.hit_cap[0] = ((batch_chunks + w0 - 1) / w0) * 64 * wps0;
+    const long long ray_limit = q.hit_cap[0] * (growth < 1 ? 1 : growth);
+    q.ray_cap[1] = q.hit_cap[0] * fan_out < ray_limit ? q.hit_cap[0] * fan_out : ray_limit;
+    for (int g = 1; g < 6; ++g) {
+        const long long c_in = N_SHARDS * ((q.ray_cap[g] + 63) / 64);
+        q.hit_cap[g] = ((c_in + waves_q - 1) / waves_q) * 64 * wps_q;
+        q.ray_cap[g + 1] = q.hit_cap[g] * fan_out < ray_limit ? q.hit_cap[g] * fan_out : ray_limit;
+    }
+    q.need_rays[0] = q.need_rays[1] = 64;
+    q.need_hits = 0;
+    for (int g = 1; g < 6; ++g)
+        if (q.ray_cap[g] * N_SHARDS > q.need_rays[g & 1]) q.need_rays[g & 1] = q.ray_cap[g] * N_SHARDS;
+    for (int g = 0; g < 6; ++g)
+        if (q.hit_cap[g] * N_SHARDS > q.need_hits) q.need_hits = q.hit_cap[g] * N_SHARDS;
+}
+
+// Equal batches instead of full ones and a short last one (a short batch costs its twelve launches all the same);
+// a batch is a whole number of 8x8-pixel blocks (spp chunks each).
+static long long even_batches(long long n_chunks, long long batch_chunks, long long spp)
+{
+    if (batch_chunks > (1ll << 25)) batch_chunks = 1ll << 25;      // samples of a batch are numbered in 32 bits
+    batch_chunks = batch_chunks / spp * spp;
+    if (batch_chunks > n_chunks) batch_chunks = n_chunks;
+    if (batch_chunks < spp) batch_chunks = spp;
+    const long long n_batches = (n_chunks + batch_chunks - 1) / batch_chunks;
+    const long long even = (n_chunks + n_batches - 1) / n_batches;
+    return (even + spp - 1) / spp * spp;
+}
+
+// The buffers a frame works in besides its inputs and outputs: the FP64 accumulation frame, the ray, hit and
+// deferred-query queues of one batch, the queue counters: device allocations of the context that only grow.
+struct FrameBuffers {
+    double *accum = nullptr;
+    RayRec *rays[2] = {nullptr, nullptr};
+    HitRec *hits[4] = {nullptr, nullptr, nullptr, nullptr};
+    HitRec *deferred[6] = {};
+    uint32_t *counts = nullptr;                 // 2 * CNT_WORDS
+    unsigned long long *totals = nullptr;       // 16
+};
+
+static int buffers_from_context(rt_ctx *ctx, const QueuePlan &q, size_t n_pixels, FrameBuffers &B)
+{
+    int rc;
+    if ((rc = ensure(&ctx->accum, &ctx->accum_values, n_pixels * 3)) != RT_OK) return rc;
+    if ((rc = ensure(&ctx->rays[0], &ctx->ray_capacity[0], (size_t)q.need_rays[0])) != RT_OK) return rc;
+    if ((rc = ensure(&ctx->rays[1], &ctx->ray_capacity[1], (size_t)q.need_rays[1])) != RT_OK) return rc;
+    for (int k = 0; k < q.hit_buffers; ++k)
+        if ((rc = ensure(&ctx->hits[k], &ctx->hit_capacity[k], (size_t)q.need_hits)) != RT_OK) return rc;
+    if (q.deferred)
+        for (int g = 0; g < 6; ++g)
+            if ((rc = ensure(&ctx->deferred[g], &ctx->deferred_capacity[g], (size_t)(q.hit_cap[g] * N_SHARDS))) != RT_OK) return rc;
+    B.accum = ctx->accum;
+    B.rays[0] = ctx->rays[0]; B.rays[1] = ctx->rays[1];
+    for (int k = 0; k < 4; ++k) B.hits[k] = ctx->hits[k];
+    for (int g = 0; g < 6; ++g) B.deferred[g] = ctx->deferred[g];
+    B.counts = ctx->counts;
+    B.totals = ctx->totals;
+    return RT_OK;
+}
+
+static void release_queues(rt_ctx *ctx)
+{
+    for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->rays[k]); ctx->rays[k] = nullptr; ctx->ray_capacity[k] = 0; }
+    for (int k = 0; k < 4; ++k) { (void)hipFree(ctx->hits[k]); ctx->hits[k] = nullptr; ctx->hit_capacity[k] = 0; }
+    for (int g = 0; g < 6; ++g) { (void)hipFree(ctx->deferred[g]); ctx->deferred[g] = nullptr; ctx->deferred_capacity[g] = 0; }
+}
+
+// How a frame is put on the device.
+enum FrameMode {
+    FRAME_HOST_OUT,      // rt_render with host output buffers (staged)
+    FRAME_DEVICE_OUT     // rt_render / rt_render_async with device output buffers
+};
+
+static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *o, const rt_frame_out *out, FrameMode mode)
 {
     if (!ctx || !cam || !o || !out) return fail(RT_ERR_INVALID, "rt_render: null argument");
     if (!ctx->has_scene) return fail(RT_ERR_INVALID, "rt_render: no scene uploaded");
@@ -607,6 +750,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const int band = o->band_rows > 0 ? o->band_rows : cam->resy;
     if (o->part < 0 || o->part >= parts) return fail(RT_ERR_INVALID, "rt_render: part out of range");
     if (ctx->pending) return fail(RT_ERR_INVALID, "rt_render: a frame is already in flight; call rt_sync first");
+    const bool noalloc = false;
+    const bool outputs_on_device = mode != FRAME_HOST_OUT;
     HIP_TRY(hipSetDevice(ctx->device));
 
     const int local_rows = local_rows_of(cam, o);
@@ -643,6 +788,25 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     P.div_band = make_fastdiv((uint32_t)band);
     P.cull_closest = may_cull ? 1 : 0;
     P.cull_shadow = (may_cull && !ctx->any_transparent_sphere) ? 1 : 0;
+
+    // ---- batch size: primary ordering is 8x8-pixel blocks, N*N samples per pixel -> (N*N) 64-sample chunks per block
+    const long long spp = (long long)N * N;
+    const long long blocks_y = ((long long)local_rows + 7) / 8;
+    const long long n_chunks = blocks_y * P.blocks_x * spp;
+    const long long default_batch = ctx->any_transparent ? (1ll << 24) : (1ll << 28);
+    const long long wanted_batch_chunks = ((ctx->batch_override > 0 ? ctx->batch_override : default_batch) + 63) / 64;
+    long long batch_chunks = even_batches(n_chunks, wanted_batch_chunks, spp);
+    if (ctx->batch_override > 0) {
+        // an explicit batch size is taken as it is (whole blocks), not evened out
+        long long b = wanted_batch_chunks;
+        if (b > (1ll << 25)) b = 1ll << 25;
+        b = b / spp * spp;
+        if (b > n_chunks) b = n_chunks;
+        if (b < spp) b = spp;
+        batch_chunks = b;
+    }
+
+    // ---- launch shape
     // The hierarchies answer "nearest / any hit over all primitives"; that equals the reference's
     // walk when every sphere is inside the root cube, and for shadow queries only when no
     // transparent sphere exists (checkOccluded3 is then order-free).
@@ -651,16 +815,15 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     int stack_entries = ctx->accel_stack + 1;
     if (stack_entries > BVH_STACK) stack_entries = BVH_STACK;
     if (stack_entries < 4) stack_entries = 4;
+    // Block size.  Large batches run one 1024-thread block per compute unit (one LDS copy of the top of the scene
+    // per compute unit); small ones, which live on latency and on many independent blocks, 256-thread blocks.
+    int block = (noalloc || batch_chunks * 64 <= (1ll << 22)) ? 256 : RT_BLOCK;
+    if (ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024) block = ctx->dbg.block_threads;
+    const int blocks_per_cu = 1024 / block, waves_per_block = block / 64;
+    P.S.stack_shift = block == 256 ? 8 : 10;
     // LDS per block: the stacks, the material and light tables, then as many top-of-tree nodes as fit
     // beside them when the compute unit holds 1024 threads (the register budget allows four waves per SIMD).
     // A tree so deep that its stacks alone do not fit keeps to the octree walk.
-    // Block size: see RT_BLOCK.  (The choice needs the batch size, which is fixed further down by the same rule.)
-    const long long frame_samples = (long long)n_pixels * N * N;
-    const long long batch_samples = ctx->batch_override > 0 ? ctx->batch_override : (ctx->any_transparent ? (1ll << 22) : (1ll << 28));
-    int block = (frame_samples < batch_samples ? frame_samples : batch_samples) <= (1ll << 22) ? 256 : RT_BLOCK;
-    if (const char *e = std::getenv("RT_BLOCK_THREADS")) block = std::atoi(e) == 1024 ? 1024 : 256;     // experiments
-    const int blocks_per_cu = 1024 / block, waves_per_block = block / 64;
-    P.S.stack_shift = block == 256 ? 8 : 10;
     const size_t lds_block = ctx->lds_per_cu / blocks_per_cu;      // LDS a block may take when a compute unit is full
     size_t lds_stack = (size_t)stack_entries * block * sizeof(int);
     if (lds_stack + 8192 > ctx->lds_per_cu) bvh_closest_ok = false;     // (a block may take a whole compute unit's LDS)
@@ -680,7 +843,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         const size_t per_block = lds_block;
         const size_t fixed = lds_stack + lds_tables + 128 + 512;
         long long room = per_block > fixed ? (long long)((per_block - fixed) / (NODE_LDS_WORDS * 4)) : 0;
-        if (const char *e = std::getenv("RT_NODE_CACHE")) room = std::atoll(e) < room ? std::atoll(e) : room;   // experiments
+        if (ctx->dbg.node_cache >= 0 && ctx->dbg.node_cache < room) room = ctx->dbg.node_cache;
         // the triangle hierarchy first, the sphere hierarchy takes what is left; split evenly when both are large
         long long nt = P.S.n_tri_nodes, ns = P.S.n_sph_nodes;
         if (!bvh_closest_ok) nt = ns = 0;
@@ -696,7 +859,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         long long left = (long long)(per_block > fixed ? per_block - fixed : 0) - (nt + ns) * NODE_LDS_WORDS * 4;
         long long tc = bvh_closest_ok && left > 0 ? left / 80 : 0;
         if (tc > ctx->n_btri) tc = ctx->n_btri;
-        if (const char *e = std::getenv("RT_TRI_CACHE")) tc = std::atoll(e) < tc ? std::atoll(e) : tc;   // experiments
+        if (ctx->dbg.tri_cache >= 0 && ctx->dbg.tri_cache < tc) tc = ctx->dbg.tri_cache;
         P.S.btri_cached = (int32_t)tc;
         P.S.lds_cache_word = (int32_t)(lds_stack / sizeof(int));
         P.S.lds_tri_word = P.S.lds_cache_word + (P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS;
@@ -709,20 +872,60 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                            (size_t)P.S.btri_cached * 80 + lds_tables + 128 + 16;
     const size_t lds_closest = lds_bvh;
     const size_t lds_shadow = lds_bvh;
+    const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
+
+    // ---- queues
+    const int rounds = ctx->dbg.rounds > 0 ? ctx->dbg.rounds : 2;        // rounds of resident blocks a queued pass is cut into
+    int max_blocks = ctx->cu_count * rounds * blocks_per_cu;
+    const int max_blocks_256 = ctx->cu_count * 8;                        // the same for kernels with 256-thread blocks
+    const long long fan_out = ctx->any_transparent ? 2 : 1;
+    QueuePlan QP;
+    FrameBuffers B;
+    bool overlap = false;
+    if (local_rows > 0 && !noalloc) {
+        // Overlap pays when a pass cannot fill the chip by itself (small frames: each pass is one
+        // ray's latency long); big batches already saturate it with one persistent grid, and there
+        // the extra ordering constraints only cost, so they run on one stream.
+        // With overlap, four hit buffers: [batch parity][generation parity], so that the shadow pass of
+        // one generation (second stream) can run beside the closest-hit pass of the next one; on one
+        // stream a single buffer serves every pass.
+        // The queues of a batch must fit the context's memory budget, and the allocations must succeed: the batch is
+        // halved until both hold.
+        for (;;) {
+            overlap = batch_chunks * 64 <= (1ll << 22) && block == 256;
+            plan_queues(QP, batch_chunks, waves_per_block, max_blocks, fan_out, ctx->growth);
+            QP.hit_buffers = overlap ? 4 : 1;
+            QP.deferred = use_lightcam;
+            const bool smallest = batch_chunks <= spp;
+            int rc = RT_OK;
+            if (QP.bytes() > ctx->queue_budget && !smallest) rc = RT_ERR_CAPACITY;
+            else if (QP.need_rays[0] >= (1ll << 32) || QP.need_rays[1] >= (1ll << 32) || QP.need_hits >= (1ll << 32)) rc = RT_ERR_CAPACITY;
+            else {
+                rc = buffers_from_context(ctx, QP, n_pixels, B);
+                if (rc != RT_OK && !smallest) release_queues(ctx);      // start over from nothing at the smaller size
+            }
+            if (rc == RT_OK) break;
+            if (smallest) return rc == RT_ERR_CAPACITY ? fail(RT_ERR_CAPACITY, "rt_render: the queues of the smallest batch exceed the memory budget") : rc;
+            batch_chunks = even_batches(n_chunks, (batch_chunks + 1) / 2, spp);
+        }
+    } else {
+        B.totals = ctx->totals;
+    }
+    const long long *hit_cap = QP.hit_cap, *ray_cap = QP.ray_cap;
+    const long long blocks0 = QP.blocks0;
 
     hipStream_t st = ctx->stream;
     HIP_TRY(hipEventRecord(ctx->ev_begin, st));
-    HIP_TRY(hipMemsetAsync(ctx->totals, 0, 16 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(B.totals, 0, 16 * sizeof(unsigned long long), st));
     ctx->ev_closest_used = ctx->ev_shadow_used = 0;
     ctx->pending_flags = o->flags;
     ctx->pending_batches = 0;
     ctx->pending_primaries = (unsigned long long)n_pixels * (unsigned long long)(N * N);
+    ctx->pending_totals = B.totals;
 
     if (local_rows > 0) {
-        int rc;
-        if ((rc = ensure(&ctx->accum, &ctx->accum_values, n_pixels * 3)) != RT_OK) return rc;
-        HIP_TRY(hipMemsetAsync(ctx->accum, 0, n_pixels * 3 * sizeof(double), st));
-        P.accum = ctx->accum;
+        HIP_TRY(hipMemsetAsync(B.accum, 0, n_pixels * 3 * sizeof(double), st));
+        P.accum = B.accum;
 
         // outputs: device pointers are used directly, host pointers go through staging buffers
         void *dst[4] = {out->rgb_f64, out->rgb_u8, out->hit_id, out->lightcam_mask};
@@ -745,68 +948,6 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         P.lc_mask = static_cast<uint8_t *>(dev[3]);
         if (dev[3]) HIP_TRY(hipMemsetAsync(dev[3], 0, bytes[3], st));
 
-        // primary ordering: 8x8-pixel blocks, N*N samples per pixel -> (N*N) 64-sample chunks per block
-        const long long blocks_y = ((long long)local_rows + 7) / 8;
-        const long long n_chunks = blocks_y * P.blocks_x * (long long)(N * N);
-        long long batch_chunks = ctx->batch_override > 0 ? (ctx->batch_override + 63) / 64
-                                                          : (ctx->any_transparent ? (1ll << 22) / 64 : (1ll << 28) / 64);
-        // a batch is a whole number of 8x8-pixel blocks (N*N chunks each), so that it begins at a block, and its
-        // samples are numbered in 32 bits
-        if (batch_chunks > (1ll << 25)) batch_chunks = 1ll << 25;
-        batch_chunks = batch_chunks / (N * N) * (N * N);
-        if (batch_chunks > n_chunks) batch_chunks = n_chunks;
-        if (batch_chunks < N * N) batch_chunks = N * N;
-        if (ctx->batch_override <= 0) {
-            // equal batches instead of full ones and a short last one (a short batch costs its twelve launches all the same)
-            const long long n_batches = (n_chunks + batch_chunks - 1) / batch_chunks;
-            const long long even = (n_chunks + n_batches - 1) / n_batches;
-            batch_chunks = (even + N * N - 1) / (N * N) * (N * N);
-        }
-
-        // Shard capacities, generation by generation: what one wave can be handed, times the waves
-        // that feed one shard, times the fan-out of a hit (reflection, plus refraction if any
-        // material is transparent).  These are upper bounds, so a push can never overflow.
-        int rounds = 2;
-        if (const char *e = std::getenv("RT_ROUNDS")) rounds = std::atoi(e) > 0 ? std::atoi(e) : 2;      // experiments
-        const int max_blocks = ctx->cu_count * rounds * blocks_per_cu;     // so many rounds of resident blocks
-        const int max_blocks_256 = ctx->cu_count * 8;                 // the same for kernels with 256-thread blocks
-        const long long fan_out = ctx->any_transparent ? 2 : 1;
-        long long blocks0 = (batch_chunks + waves_per_block - 1) / waves_per_block;
-        if (blocks0 > max_blocks) blocks0 = max_blocks;
-        const long long waves_q = (long long)max_blocks * waves_per_block, wps_q = ((max_blocks + N_SHARDS - 1) / N_SHARDS) * (long long)waves_per_block;
-        long long hit_cap[6], ray_cap[7];
-        ray_cap[0] = 0;
-        {
-            const long long w0 = blocks0 * waves_per_block, wps0 = ((blocks0 + N_SHARDS - 1) / N_SHARDS) * waves_per_block;
-            hit_cap[0] = ((batch_chunks + w0 - 1) / w0) * 64 * wps0;
-            ray_cap[1] = hit_cap[0] * fan_out;
-        }
-        for (int g = 1; g < 6; ++g) {
-            const long long c_in = N_SHARDS * ((ray_cap[g] + 63) / 64);
-            hit_cap[g] = ((c_in + waves_q - 1) / waves_q) * 64 * wps_q;
-            ray_cap[g + 1] = hit_cap[g] * fan_out;
-        }
-        long long need_rays[2] = {0, 0}, need_hits = 0;
-        for (int g = 1; g < 6; ++g) if (ray_cap[g] * N_SHARDS > need_rays[g & 1]) need_rays[g & 1] = ray_cap[g] * N_SHARDS;
-        for (int g = 0; g < 6; ++g) if (hit_cap[g] * N_SHARDS > need_hits) need_hits = hit_cap[g] * N_SHARDS;
-        if (need_rays[0] >= (1ll << 32) || need_rays[1] >= (1ll << 32) || need_hits >= (1ll << 32))
-            return fail(RT_ERR_INVALID, "rt_render: batch too large for 32-bit queue indices");
-        if ((rc = ensure(&ctx->rays[0], &ctx->ray_capacity[0], (size_t)(need_rays[0] ? need_rays[0] : 64))) != RT_OK) return rc;
-        if ((rc = ensure(&ctx->rays[1], &ctx->ray_capacity[1], (size_t)(need_rays[1] ? need_rays[1] : 64))) != RT_OK) return rc;
-        // Overlap pays when a pass cannot fill the chip by itself (small frames: each pass is one
-        // ray's latency long); big batches already saturate it with one persistent grid, and there
-        // the extra ordering constraints only cost, so they run on one stream.
-        const bool overlap = batch_chunks * 64 <= (1ll << 22) && block == 256;
-        // with overlap, four hit buffers: [batch parity][generation parity], so that the shadow pass of
-        // one generation (second stream) can run beside the closest-hit pass of the next one; on one
-        // stream a single buffer serves every pass
-        for (int k = 0; k < (overlap ? 4 : 1); ++k)
-            if ((rc = ensure(&ctx->hits[k], &ctx->hit_capacity[k], (size_t)need_hits)) != RT_OK) return rc;
-        const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
-        if (use_lightcam)
-            for (int g = 0; g < 6; ++g)
-                if ((rc = ensure(&ctx->deferred[g], &ctx->deferred_capacity[g], (size_t)(hit_cap[g] * N_SHARDS))) != RT_OK) return rc;
-
         // Two streams.  A: counters memset, closest-hit passes C0..C5 of every batch, in order.
         // B: shadow/shading passes S0..S5 and the batch's counter roll-up.  S_g waits for C_g; C_g+2
         // waits for S_g (it re-uses S_g's hit buffer); a batch's memset waits for the roll-up of
@@ -818,15 +959,15 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         for (long long t0 = 0; t0 < n_chunks; t0 += batch_chunks, ++batch_no) {
             const long long t1 = (t0 + batch_chunks < n_chunks) ? t0 + batch_chunks : n_chunks;
             const int par = (int)(batch_no & 1);
-            uint32_t *counts = ctx->counts + (size_t)par * CNT_WORDS;
+            uint32_t *counts = B.counts + (size_t)par * CNT_WORDS;
             if (batch_no >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[par], 0));
             HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
             for (int g = 0; g < 6; ++g) {
                 QueueSet Q{};
-                Q.rays_in = ctx->rays[g & 1];
-                Q.rays_out = ctx->rays[(g + 1) & 1];
-                Q.hits = ctx->hits[overlap ? par * 2 + (g & 1) : 0];
-                Q.deferred = ctx->deferred[g];
+                Q.rays_in = B.rays[g & 1];
+                Q.rays_out = B.rays[(g + 1) & 1];
+                Q.hits = B.hits[overlap ? par * 2 + (g & 1) : 0];
+                Q.deferred = B.deferred[g];
                 Q.counts = counts;
                 Q.in_shard_cap = (uint32_t)ray_cap[g];
                 Q.out_shard_cap = (uint32_t)(g < 5 ? ray_cap[g + 1] : 0);
@@ -870,11 +1011,11 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             if (use_lightcam) {
                 // the density queries of all six generations in one launch, after the last shadow pass
                 LightcamQueues L{};
-                for (int g = 0; g < 6; ++g) { L.deferred[g] = ctx->deferred[g]; L.shard_cap[g] = (uint32_t)hit_cap[g]; }
+                for (int g = 0; g < 6; ++g) { L.deferred[g] = B.deferred[g]; L.shard_cap[g] = (uint32_t)hit_cap[g]; }
                 L.counts = counts;
                 hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks_256), dim3(256), 0, sb, P, L);
             }
-            hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, sb, counts, ctx->totals, P.S.n_lights);
+            hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, sb, counts, B.totals, P.S.n_lights);
             HIP_TRY(hipEventRecord(ctx->ev_batch[par], sb));
             ctx->pending_batches++;
         }
@@ -886,7 +1027,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             const long long n_values = (long long)n_pixels * 3;
             long long blocks = (n_values + 255) / 256;
             if (blocks > max_blocks_256) blocks = max_blocks_256;
-            hipLaunchKernelGGL(k_finalize, dim3((unsigned)blocks), dim3(256), 0, st, ctx->accum, n_values, N * N,
+            hipLaunchKernelGGL(k_finalize, dim3((unsigned)blocks), dim3(256), 0, st, B.accum, n_values, N * N,
                                static_cast<double *>(dev[0]), static_cast<uint8_t *>(dev[1]));
             HIP_TRY(hipGetLastError());
         }
@@ -907,7 +1048,7 @@ extern "C" int rt_sync(rt_ctx *ctx, rt_stats *stats)
     ctx->pending = false;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     unsigned long long tot[16];
-    HIP_TRY(hipMemcpy(tot, ctx->totals, sizeof tot, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tot, ctx->pending_totals, sizeof tot, hipMemcpyDeviceToHost));
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         tot[0] += ctx->pending_primaries;   // generation 0 is counted on the host
@@ -945,23 +1086,61 @@ extern "C" int rt_sync(rt_ctx *ctx, rt_stats *stats)
             stats->shadow_launches = ctx->ev_shadow_used;
         }
     }
-    if (tot[15]) return fail(RT_ERR_CAPACITY, "rt_render: a ray queue overflowed; the frame is incomplete");
+    if (tot[15]) {
+        // the next frame of this scene gets queues twice as deep (up to the worst case, 32 rays per primary in a generation)
+        if (ctx->growth < 32) ctx->growth *= 2;
+        return fail(RT_ERR_CAPACITY, "rt_render: a ray queue overflowed; the frame is incomplete (the context has doubled its queue depth "
+                                     "for the next frame)");
+    }
     return RT_OK;
 }
 
 extern "C" int rt_render_async(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *opts, const rt_frame_out *out)
 {
     if (out && !out->on_device) return fail(RT_ERR_INVALID, "rt_render_async: outputs must be device memory");
-    return enqueue_frame(ctx, cam, opts, out, true);
+    return enqueue_frame(ctx, cam, opts, out, FRAME_DEVICE_OUT);
+}
+
+static void abandon_frame(rt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream2);
+    ctx->pending = false;
 }
 
 extern "C" int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *opts, const rt_frame_out *out,
                          rt_stats *stats)
 {
-    int rc = enqueue_frame(ctx, cam, opts, out, out && out->on_device);
-    if (rc != RT_OK) {
-        if (ctx) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); ctx->pending = false; }
-        return rc;
+    // A frame whose ray tree outgrew the queues is rendered again with deeper ones (rt_sync has doubled the depth);
+    // five doublings reach the worst case, which cannot overflow.
+    for (int attempt = 0;; ++attempt) {
+        int rc = enqueue_frame(ctx, cam, opts, out, (out && out->on_device) ? FRAME_DEVICE_OUT : FRAME_HOST_OUT);
+        if (rc != RT_OK) { abandon_frame(ctx); return rc; }
+        rc = rt_sync(ctx, stats);
+        if (rc != RT_ERR_CAPACITY || attempt >= 5) return rc;
     }
-    return rt_sync(ctx, stats);
+}
+
+extern "C" int rt_set_memory_budget(rt_ctx *ctx, size_t bytes)
+{
+    if (!ctx) return fail(RT_ERR_INVALID, "rt_set_memory_budget: null argument");
+    ctx->queue_budget = bytes ? bytes : RT_DEFAULT_QUEUE_BUDGET;
+    return RT_OK;
+}
+
+extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name) return fail(RT_ERR_INVALID, "rt_debug_set_option: null argument");
+    const std::string n(name);
+    if (n == "block_threads") ctx->dbg.block_threads = (int)value;
+    else if (n == "node_cache") ctx->dbg.node_cache = value;
+    else if (n == "tri_cache") ctx->dbg.tri_cache = value;
+    else if (n == "rounds") ctx->dbg.rounds = (int)value;
+    else if (n == "verbose") ctx->dbg.verbose = value != 0;
+    else if (n == "leaf_max") ctx->dbg.leaf_max = (int)value;
+    else if (n == "split_budget") ctx->dbg.split_budget = (int)value;
+    else if (n == "queue_growth") ctx->growth = value < 1 ? 1 : (value > 32 ? 32 : (int)value);
+    else return fail(RT_ERR_INVALID, "rt_debug_set_option: unknown option '" + n + "'");
+    return RT_OK;
 }

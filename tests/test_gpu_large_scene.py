@@ -57,12 +57,11 @@ def test_height_field_with_spheres(tmp_path):
         assert np.array_equal(part["rgb_u8"], g["rgb_u8"][rows])
     # the same frame through the large-frame configuration (one 1024-thread block per compute unit, deep stacks
     # beside a partial node and record cache in LDS), which a frame this small does not select by itself
-    import os
-    os.environ["RT_BLOCK_THREADS"] = "1024"
+    gpu.set_option("block_threads", 1024)
     try:
         big = gpu.render(cam, flags=rt.FLAG_KEEP_ZERO_WEIGHT)
     finally:
-        del os.environ["RT_BLOCK_THREADS"]
+        gpu.set_option("block_threads", 0)
     assert np.array_equal(big["hit_id"], g["hit_id"])
     assert np.array_equal(big["rgb_u8"], g["rgb_u8"])
     assert big["stats"]["closest_rays"] == g["stats"]["closest_rays"] and big["stats"]["shadow_rays"] == g["stats"]["shadow_rays"]

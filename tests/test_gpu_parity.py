@@ -193,16 +193,15 @@ def test_row_band_partition_reassembles(gpu, oracle_frame):
 def test_block_sizes_agree(gpu, scene):
     """Large frames run 1024-thread blocks with one LDS copy of the scene's top per compute unit, small ones
     256-thread blocks: the same frame through both."""
-    import os
     s = load_scene(gpu, scene)
     cam = s.camera(192, 160)
     frames = []
-    for block in ("256", "1024"):
-        os.environ["RT_BLOCK_THREADS"] = block
+    for block in (256, 1024):
+        gpu.set_option("block_threads", block)
         try:
             frames.append(gpu.render(cam, num_samples=2, flags=rt.FLAG_KEEP_ZERO_WEIGHT))
         finally:
-            del os.environ["RT_BLOCK_THREADS"]
+            gpu.set_option("block_threads", 0)
     a, b = frames
     assert np.array_equal(a["hit_id"], b["hit_id"])
     assert np.array_equal(a["rgb_u8"], b["rgb_u8"])
@@ -224,6 +223,75 @@ def test_small_batches_equal_one_batch(gpu):
     assert np.array_equal(a["rgb_u8"], b["rgb_u8"])
     assert a["stats"]["closest_rays"] == b["stats"]["closest_rays"]
     assert a["stats"]["shadow_rays"] == b["stats"]["shadow_rays"]
+
+
+def test_queue_overflow_is_detected_and_rendered_again(gpu, oracle_frame):
+    """Ray queues are sized for a multiple of the primary count per generation, not for the 32-fold worst case.
+    With the multiple forced to 1 the refraction rays of refract.nff outgrow them: the asynchronous path reports
+    RT_ERR_CAPACITY (and deepens the queues for the next frame), rt_render repeats the frame by itself."""
+    import torch
+    s = load_scene(gpu, "refract")
+    cam = s.camera(256, 256)
+    o = oracle_frame("refract", res=(256, 256))
+    u8 = torch.zeros((cam.resy, cam.resx, 3), dtype=torch.uint8, device="cuda")
+    gpu.set_option("queue_growth", 1)
+    with pytest.raises(rt.RtError) as e:
+        gpu.render_device(cam, rgb_u8_ptr=u8.data_ptr(), flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    assert e.value.code == -4
+    st = gpu.render_device(cam, rgb_u8_ptr=u8.data_ptr(), flags=rt.FLAG_KEEP_ZERO_WEIGHT)     # depth 2 now: complete
+    assert st["queue_overflow"] == 0
+    assert np.array_equal(u8.cpu().numpy(), o["rgb_u8"])
+    gpu.set_option("queue_growth", 1)
+    g = gpu.render(cam, flags=rt.FLAG_KEEP_ZERO_WEIGHT)           # overflows once, is rendered again inside the call
+    assert_frames_match(g, o)
+    assert g["stats"]["queue_overflow"] == 0
+    assert g["stats"]["closest_rays"] == o["counters"]["closest_rays"]
+    load_scene(gpu, "refract")                                    # an upload restores the default depth
+
+
+def test_memory_budget_only_changes_the_batching(gpu):
+    s = load_scene(gpu, "balls")
+    cam = s.camera(320, 320)
+    a = gpu.render(cam)
+    gpu.set_memory_budget(24 << 20)
+    try:
+        b = gpu.render(cam)
+    finally:
+        gpu.set_memory_budget(0)
+    assert b["stats"]["batches"] > a["stats"]["batches"]
+    assert np.array_equal(a["hit_id"], b["hit_id"])
+    assert np.array_equal(a["rgb_u8"], b["rgb_u8"])
+    assert a["stats"]["closest_rays"] == b["stats"]["closest_rays"] and a["stats"]["shadow_rays"] == b["stats"]["shadow_rays"]
+
+
+def test_too_many_light_cameras_is_an_error_not_a_silent_frame(gpu):
+    """More (transparent sphere, light) pairs than the library sets up cameras for: the call fails with a capacity
+    error instead of returning a frame without the light-camera term; RT_FLAG_NO_LIGHTCAM still renders."""
+    import os
+    import tempfile
+    lines = ["b 0.1 0.1 0.2", "v", "from 0 -12 4", "at 0 0 0", "up 0 0 1", "angle 40", "hither 1", "resolution 48 48"]
+    for k in range(5):
+        lines.append("l %g 6 9" % (k - 2.0))
+    lines.append("f 0.8 0.8 0.8 0.9 0.1 10 0 1")
+    lines += ["p 4", "-8 -8 -1", "8 -8 -1", "8 8 -1", "-8 8 -1"]
+    lines.append("f 0.9 0.9 1 0.1 0.2 50 0.9 1.3")
+    n = 0
+    for i in range(30):
+        for j in range(28):
+            lines.append("s %g %g 0 0.1" % (-4 + 0.27 * i, -4 + 0.27 * j))
+            n += 1
+    assert n * 5 > 4096
+    path = os.path.join(tempfile.mkdtemp(), "many_glass.nff")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    s = rt.Scene.load(path)
+    gpu.upload(s)
+    with pytest.raises(rt.RtError) as e:
+        gpu.render(s.camera())
+    assert e.value.code == -4 and "light cameras" in str(e.value)
+    g = gpu.render(s.camera(), flags=rt.FLAG_NO_LIGHTCAM)
+    assert g["lightcam_mask"].any()
+    s.close()
 
 
 def test_bad_arguments_are_errors(gpu):
