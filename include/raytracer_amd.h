@@ -188,6 +188,22 @@ int rt_set_memory_budget(rt_ctx *ctx, size_t bytes);
  * If a frame outgrows them, rt_sync returns RT_ERR_CAPACITY (the outputs are incomplete) and the context doubles
  * the multiple for its next frame; rt_render does that re-rendering by itself and only returns a complete frame. */
 
+/* rt_render for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and results as
+ * rt_render with device output buffers (out->on_device must be 1), but it calls no hipMalloc/hipFree and creates
+ * no events: accumulation frame, counters and queues live in a static device array of rt_noalloc_scratch_bytes()
+ * (128 MiB) that every GPU holds once per process.  Limits, each an error and never a fallback:
+ *   - RT_ERR_CAPACITY when the part's pixels * 24 bytes plus the smallest batch's queues exceed the array
+ *     (about 5 M pixels; render larger frames in parts, see rt_render_opts);
+ *   - RT_ERR_CAPACITY from a queue overflow is returned as it is (no automatic second attempt);
+ *   - RT_ERR_UNSUPPORTED with RT_FLAG_TIMING, and when the scene's light cameras are not built yet (building
+ *     allocates): render one frame with rt_render first or pass RT_FLAG_NO_LIGHTCAM.
+ * All contexts of one GPU share the array and it keeps the last call's contents: calls that overlap in time on one
+ * GPU race; calls one after the other, from any context, are fine. */
+int rt_render_noalloc(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *opts, const rt_frame_out *out,
+                      rt_stats *stats);
+int rt_noalloc_scratch_bytes(size_t *bytes);
+
 /* Diagnostic: experiment switches of one context, none of which changes a result.  Names: "block_threads" (256 or
  * 1024, 0 = per-frame choice), "node_cache", "tri_cache" (caps on what is copied into LDS, -1 = none), "rounds",
  * "verbose", "queue_growth" (1..32), and for the next rt_upload_scene "leaf_max" (1..4), "split_budget" (percent). */

@@ -119,6 +119,9 @@ _SIGNATURES = {
     "rt_sync": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rt_set_batch": (C.c_int, [C.c_void_p, C.c_int64]),
     "rt_set_memory_budget": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rt_render_noalloc": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.POINTER(FrameOut),
+                                    C.POINTER(Stats)]),
+    "rt_noalloc_scratch_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
     "rt_debug_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "rt_debug_intersect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.c_double, C.c_double, C.POINTER(C.c_double)]),
@@ -272,6 +275,12 @@ class Scene:
         return np.ctypeslib.as_array(C.cast(d.lights, C.POINTER(C.c_double)), shape=(d.n_lights, 8))
 
 
+def noalloc_scratch_bytes():
+    n = C.c_size_t()
+    _check(load().rt_noalloc_scratch_bytes(C.byref(n)))
+    return n.value
+
+
 def part_rows(cam, band_rows=0, n_parts=1, part=0):
     opts = RenderOpts(num_samples=1, band_rows=band_rows, n_parts=n_parts, part=part)
     rows = C.c_int32()
@@ -323,6 +332,16 @@ class Renderer:
     def set_option(self, name, value):
         """Experiment switch of this context (rt_debug_set_option)."""
         _check(load().rt_debug_set_option(self._ctx, name.encode(), int(value)))
+
+    def render_noalloc(self, cam, rgb_f64_ptr=0, rgb_u8_ptr=0, hit_id_ptr=0, mask_ptr=0, num_samples=1, aperture=0.0,
+                       flags=0, seed=0, band_rows=0, n_parts=1, part=0):
+        """rt_render_noalloc: device output buffers, work memory from the library's static scratch."""
+        opts = self._opts(num_samples, aperture, flags, seed, band_rows, n_parts, part)
+        out = FrameOut(rgb_f64=rgb_f64_ptr or None, rgb_u8=rgb_u8_ptr or None, hit_id=hit_id_ptr or None,
+                       lightcam_mask=mask_ptr or None, on_device=1)
+        stats = Stats()
+        _check(load().rt_render_noalloc(self._ctx, C.byref(cam), C.byref(opts), C.byref(out), C.byref(stats)))
+        return stats.as_dict()
 
     @staticmethod
     def _opts(num_samples, aperture, flags, seed, band_rows, n_parts, part):

@@ -49,6 +49,20 @@ extern "C" const char *rt_last_error(void) { return g_error.c_str(); }
             return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
     } while (0)
 
+// ------------------------------------------------------------------ static scratch
+// Work memory of rt_render_noalloc, the entry point for callers that cannot allocate: the accumulation frame, the
+// queue counters and one batch's ray, hit and deferred-query queues are carved out of this array instead of
+// device allocations.  It is part of the code object, so every GPU the library runs on holds its own copy until
+// the process ends.  In host code the name is only a handle: rt_create asks the runtime for the array's address
+// on its device (hipGetSymbolAddress) and everything else -- kernel arguments, memsets -- uses that pointer.
+#define RT_NOALLOC_SCRATCH_BYTES (128u << 20)
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+#define RT_MAX_DEVICES 64
+namespace {
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[RT_MAX_DEVICES] = {};       // per device: address of that device's copy of `scratch`
+}  // namespace
+
 // Queue memory one context may take unless rt_set_memory_budget says otherwise.
 #define RT_DEFAULT_QUEUE_BUDGET ((size_t)96 << 30)
 
@@ -99,6 +113,7 @@ struct rt_ctx {
     int64_t batch_override = 0;
     size_t queue_budget = RT_DEFAULT_QUEUE_BUDGET;
     int growth = 2;                        // ray queues hold this many times the first generation's capacity (plan_queues)
+    void *scratch = nullptr;               // this device's copy of the static scratch array
     DebugOptions dbg;
     // pending async frame
     unsigned long long *pending_totals = nullptr;
@@ -186,6 +201,16 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
                                  (const void *)k_closest<false, false>, (const void *)k_shadow<true>,       (const void *)k_shadow<false>,
                                  (const void *)k_shadow_hybrid};
         for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    }
+    if (device_id < RT_MAX_DEVICES) {
+        // once per device, with that device current: where this GPU keeps its copy of the static scratch
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device_id]) {
+            void *p = nullptr;
+            HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            g_scratch_ptr[device_id] = p;
+        }
+        ctx->scratch = g_scratch_ptr[device_id];
     }
     *out = ctx;
     return RT_OK;
@@ -697,7 +722,8 @@ static long long even_batches(long long n_chunks, long long batch_chunks, long l
 }
 
 // The buffers a frame works in besides its inputs and outputs: the FP64 accumulation frame, the ray, hit and
-// deferred-query queues of one batch, the queue counters: device allocations of the context that only grow.
+// deferred-query queues of one batch, the queue counters.  rt_render / rt_render_async take them from the
+// context (device allocations that only grow); rt_render_noalloc carves them out of the device's static scratch.
 struct FrameBuffers {
     double *accum = nullptr;
     RayRec *rays[2] = {nullptr, nullptr};
@@ -734,10 +760,35 @@ static void release_queues(rt_ctx *ctx)
     for (int g = 0; g < 6; ++g) { (void)hipFree(ctx->deferred[g]); ctx->deferred[g] = nullptr; ctx->deferred_capacity[g] = 0; }
 }
 
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+static size_t scratch_need(const QueuePlan &q, size_t n_pixels)
+{
+    size_t b = align256(n_pixels * 3 * sizeof(double)) + align256(2 * CNT_WORDS * sizeof(uint32_t)) + align256(16 * sizeof(unsigned long long));
+    b += align256((size_t)q.need_rays[0] * sizeof(RayRec)) + align256((size_t)q.need_rays[1] * sizeof(RayRec));
+    b += align256((size_t)q.need_hits * sizeof(HitRec));
+    if (q.deferred)
+        for (int g = 0; g < 6; ++g) b += align256((size_t)(q.hit_cap[g] * N_SHARDS) * sizeof(HitRec));
+    return b;
+}
+static void buffers_from_scratch(unsigned char *base, const QueuePlan &q, size_t n_pixels, FrameBuffers &B)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) { unsigned char *p = base + off; off += align256(bytes); return p; };
+    B.accum = reinterpret_cast<double *>(take(n_pixels * 3 * sizeof(double)));
+    B.counts = reinterpret_cast<uint32_t *>(take(2 * CNT_WORDS * sizeof(uint32_t)));
+    B.totals = reinterpret_cast<unsigned long long *>(take(16 * sizeof(unsigned long long)));
+    B.rays[0] = reinterpret_cast<RayRec *>(take((size_t)q.need_rays[0] * sizeof(RayRec)));
+    B.rays[1] = reinterpret_cast<RayRec *>(take((size_t)q.need_rays[1] * sizeof(RayRec)));
+    B.hits[0] = reinterpret_cast<HitRec *>(take((size_t)q.need_hits * sizeof(HitRec)));
+    if (q.deferred)
+        for (int g = 0; g < 6; ++g) B.deferred[g] = reinterpret_cast<HitRec *>(take((size_t)(q.hit_cap[g] * N_SHARDS) * sizeof(HitRec)));
+}
+
 // How a frame is put on the device.
 enum FrameMode {
     FRAME_HOST_OUT,      // rt_render with host output buffers (staged)
-    FRAME_DEVICE_OUT     // rt_render / rt_render_async with device output buffers
+    FRAME_DEVICE_OUT,    // rt_render / rt_render_async with device output buffers
+    FRAME_NOALLOC        // rt_render_noalloc: device outputs, work buffers from the static scratch, no allocation of any kind
 };
 
 static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *o, const rt_frame_out *out, FrameMode mode)
@@ -750,8 +801,11 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const int band = o->band_rows > 0 ? o->band_rows : cam->resy;
     if (o->part < 0 || o->part >= parts) return fail(RT_ERR_INVALID, "rt_render: part out of range");
     if (ctx->pending) return fail(RT_ERR_INVALID, "rt_render: a frame is already in flight; call rt_sync first");
-    const bool noalloc = false;
+    const bool noalloc = mode == FRAME_NOALLOC;
     const bool outputs_on_device = mode != FRAME_HOST_OUT;
+    if (noalloc && (o->flags & RT_FLAG_TIMING))
+        return fail(RT_ERR_UNSUPPORTED, "rt_render_noalloc: RT_FLAG_TIMING creates events and is not available here");
+    if (noalloc && !ctx->scratch) return fail(RT_ERR_DEVICE, "rt_render_noalloc: the static scratch of this device was not located");
     HIP_TRY(hipSetDevice(ctx->device));
 
     const int local_rows = local_rows_of(cam, o);
@@ -765,6 +819,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         const uint32_t lc_flags = o->flags & RT_FLAG_PHONG_NORMALS;
         const bool want_lc = !(o->flags & RT_FLAG_NO_LIGHTCAM) && ctx->any_transparent_sphere && !ctx->h_lights.empty();
         if (want_lc && (!ctx->lc_built || ctx->lc_built_flags != lc_flags)) {
+            if (noalloc)
+                return fail(RT_ERR_UNSUPPORTED, "rt_render_noalloc: this scene's light cameras are not built yet for these flags (building "
+                                                "allocates); render one frame with rt_render first, or pass RT_FLAG_NO_LIGHTCAM");
             int rc = build_lightcams(ctx, lc_flags, may_cull);
             if (rc != RT_OK) return rc;
         }
@@ -908,8 +965,40 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             if (smallest) return rc == RT_ERR_CAPACITY ? fail(RT_ERR_CAPACITY, "rt_render: the queues of the smallest batch exceed the memory budget") : rc;
             batch_chunks = even_batches(n_chunks, (batch_chunks + 1) / 2, spp);
         }
+    } else if (local_rows > 0) {
+        // The static scratch holds the accumulation frame, the counters and one batch's queues.  Among the grids of
+        // queued passes that fit, the one that keeps most waves busy wins: a smaller grid has smaller per-shard floors.
+        long long best_score = -1;
+        QueuePlan best;
+        const int grids[] = {ctx->cu_count * 4, ctx->cu_count * 2, ctx->cu_count, ctx->cu_count / 2, N_SHARDS};
+        for (int grid : grids) {
+            if (grid < 1) continue;
+            long long bc = even_batches(n_chunks, wanted_batch_chunks, spp);
+            for (;;) {
+                QueuePlan q;
+                plan_queues(q, bc, waves_per_block, grid, fan_out, ctx->growth);
+                q.hit_buffers = 1;
+                q.deferred = use_lightcam;
+                if (scratch_need(q, n_pixels) <= RT_NOALLOC_SCRATCH_BYTES && q.need_hits < (1ll << 32)) {
+                    const long long waves = (long long)grid * waves_per_block;
+                    const long long score = (bc < waves ? bc : waves) * 4 + (bc >= waves ? 1 : 0) * (bc / waves < 1000 ? bc / waves : 1000);
+                    if (score > best_score) { best_score = score; best = q; }
+                    break;
+                }
+                if (bc <= spp) break;
+                bc = even_batches(n_chunks, (bc + 1) / 2, spp);
+            }
+        }
+        if (best_score < 0)
+            return fail(RT_ERR_CAPACITY, "rt_render_noalloc: this frame does not fit the static scratch of " +
+                                             std::to_string(RT_NOALLOC_SCRATCH_BYTES >> 20) + " MiB (" + std::to_string(n_pixels * 24 >> 20) +
+                                             " MiB of it for the accumulation frame alone); render it in parts or use rt_render");
+        QP = best;
+        batch_chunks = QP.batch_chunks;
+        max_blocks = QP.max_blocks;
+        buffers_from_scratch(static_cast<unsigned char *>(ctx->scratch), QP, n_pixels, B);
     } else {
-        B.totals = ctx->totals;
+        B.totals = noalloc ? reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(ctx->scratch)) : ctx->totals;
     }
     const long long *hit_cap = QP.hit_cap, *ray_cap = QP.ray_cap;
     const long long blocks0 = QP.blocks0;
@@ -1120,6 +1209,22 @@ extern "C" int rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         rc = rt_sync(ctx, stats);
         if (rc != RT_ERR_CAPACITY || attempt >= 5) return rc;
     }
+}
+
+extern "C" int rt_render_noalloc(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts *opts, const rt_frame_out *out,
+                                 rt_stats *stats)
+{
+    if (out && !out->on_device) return fail(RT_ERR_INVALID, "rt_render_noalloc: outputs must be device memory");
+    int rc = enqueue_frame(ctx, cam, opts, out, FRAME_NOALLOC);
+    if (rc != RT_OK) { abandon_frame(ctx); return rc; }
+    return rt_sync(ctx, stats);
+}
+
+extern "C" int rt_noalloc_scratch_bytes(size_t *bytes)
+{
+    if (!bytes) return fail(RT_ERR_INVALID, "rt_noalloc_scratch_bytes: null argument");
+    *bytes = RT_NOALLOC_SCRATCH_BYTES;
+    return RT_OK;
 }
 
 extern "C" int rt_set_memory_budget(rt_ctx *ctx, size_t bytes)
