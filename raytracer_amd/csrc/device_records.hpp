@@ -143,6 +143,7 @@ struct QueueSet {
                                      // block of 8x8 pixels (chunk_begin is a multiple of N*N)
     int64_t block_row0;              // PRIMARY only: row and column, in 8x8-pixel blocks, of the batch's first block
     int32_t block_col0;
+    unsigned long long *totals;      // the one-launch kernel only: the frame's ray statistics (16 words)
 };
 
 // A found primitive is named by its record slot: a triangle slot, or a sphere slot with this bit set.

@@ -31,6 +31,24 @@ DEV void walk_count_flush(WalkCount &c, int base)
 #define WC_WAVE(cnt, field) ((void)0)
 #endif
 
+// With -DRT_STAMP the traversal kernels record, per wave and for its first chunk, the shader clock at fixed points
+// (rt_debug_stamps reads them): where a pass of a small frame spends its time.  Normal builds carry none of it.
+#ifdef RT_STAMP
+#define RT_STAMP_WAVES 16384
+#define RT_STAMP_SLOTS 12
+__device__ unsigned long long g_stamps[RT_STAMP_WAVES * RT_STAMP_SLOTS];
+__device__ int g_stamp_select;      // which launches record: kind * 8 + generation (kind 0 closest hit, 1 shadow)
+DEV void stamp_at(int k, int sel)
+{
+    const unsigned long long w = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (sel == g_stamp_select && (threadIdx.x & 63) == 0 && w < RT_STAMP_WAVES && g_stamps[w * RT_STAMP_SLOTS + k] == 0)
+        g_stamps[w * RT_STAMP_SLOTS + k] = __builtin_amdgcn_s_memrealtime();
+}
+#define STAMP(k) stamp_at(k, STAMP_SEL)
+#else
+#define STAMP(k) ((void)0)
+#endif
+
 // Stack of pending nodes in LDS: entry k of a lane lives at stack[k * block size + thread-in-block], so a
 // wave's push or pop touches 64 consecutive banks.
 #define BVH_STACK 64

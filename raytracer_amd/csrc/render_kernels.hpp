@@ -15,15 +15,106 @@
 #include "queues.hpp"
 #include "shading.hpp"
 
+// The camera's 16 doubles go to LDS once per block and are read back per chunk.  As kernel
+// arguments they would occupy 32 scalar registers for the whole kernel; the scalar file is
+// already over-subscribed by the scene's pointers, and every value spilled from it costs a
+// vector instruction each time it is brought back (a seventh of the primary kernel's vector work).
+DEV void camera_to_lds(const FrameParams &P)
+{
+    double *cw = reinterpret_cast<double *>(&s_lds[P.S.lds_cam_word]);
+    for (int k = 0; k < 3; ++k) { cw[k] = P.cam.u[k]; cw[3 + k] = P.cam.v[k]; cw[6 + k] = P.cam.w[k]; cw[9 + k] = P.cam.e[k]; }
+    cw[12] = P.cam.d; cw[13] = P.cam.l; cw[14] = P.cam.t; cw[15] = P.cam.pix_width;
+}
+
+// Ray generation for position `lane` of 64-sample chunk `chunk` of a batch (Camera.h:112-230): stratified
+// sub-samples with jitter, depth of field.  The camera's 16 doubles are read from LDS (lds_cam_word), where
+// thread 0 of the block has put them.
+// Primary ordering: pixels in 8x8 blocks (row-major inside a block), the N*N samples of a
+// pixel in consecutive positions; a wave takes 64 consecutive positions.
+// Positions are counted from the batch's first block, which keeps them in 32 bits, and every
+// division is by a number fixed for the launch (a multiplication, see FastDiv).
+DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, int lane, bool *active_out, d3 *o_out, d3 *d_out,
+                     uint32_t *pixel_out, bool *first_out)
+{
+    const int N = P.N;
+    const uint32_t rel = (uint32_t)chunk * 64u + (uint32_t)lane;
+    const uint32_t spp = (uint32_t)(N * N);
+    const uint32_t pseq = fast_div(rel, P.div_spp);              // pixel, counted from the batch's first
+    const int smp = (int)(rel - pseq * spp);
+    const int within = (int)(pseq & 63u);
+    const uint32_t col = (uint32_t)Q.block_col0 + (pseq >> 6);   // block column, not yet wrapped into the row
+    const uint32_t wraps = fast_div(col, P.div_blocks_x);
+    const int bx = (int)(col - wraps * (uint32_t)P.blocks_x);
+    const long long by = Q.block_row0 + wraps;
+    const int j = bx * 8 + (within & 7);
+    const long long lrow_ll = by * 8 + (within >> 3);
+    const int lrow = lrow_ll < P.local_rows ? (int)lrow_ll : P.local_rows;     // beyond the part: inactive below
+    const int si = (int)fast_div((uint32_t)smp, P.div_n), sj = smp - si * N;
+    *active_out = j < P.cam.resx && lrow < P.local_rows;
+    const int i = global_row(P, lrow);
+    *pixel_out = (uint32_t)lrow * (uint32_t)P.cam.resx + (uint32_t)j;
+    *first_out = (si == 0 && sj == 0);
+    struct { double d, l, t, pix_width; int resx; } c;
+    d3 u, v, w, e;
+    {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const __attribute__((address_space(3))) v2d *cw =
+            (const __attribute__((address_space(3))) v2d *)((__attribute__((address_space(3))) const int *)s_lds + P.S.lds_cam_word);
+        const v2d c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3], c4 = cw[4], c5 = cw[5], c6 = cw[6], c7 = cw[7];
+        u = mk3(c0.x, c0.y, c1.x); v = mk3(c1.y, c2.x, c2.y); w = mk3(c3.x, c3.y, c4.x); e = mk3(c4.y, c5.x, c5.y);
+        c.d = c6.x; c.l = c6.y; c.t = c7.x; c.pix_width = c7.y;
+        c.resx = P.cam.resx;
+    }
+    const uint32_t gpix = (uint32_t)i * (uint32_t)c.resx + (uint32_t)j;
+    const uint32_t sample = (uint32_t)(si * N + sj);
+    double p, q, r;
+    if (N > 1) {
+        double spw = c.pix_width / N;
+        double randX = normed_rand(gpix, sample, 0, P.seed);
+        double randY = normed_rand(gpix, sample, 1, P.seed);
+        randX -= .5;
+        randY -= .5;
+        double edgeX = (j - .5) * c.pix_width;
+        double edgeY = (i - .5) * c.pix_width;
+        double j_m = edgeX + sj * spw + .5 * spw;
+        double i_m = edgeY + si * spw + .5 * spw;
+        randX *= spw;
+        randY *= spw;
+        j_m += randX;
+        i_m += randY;
+        p = c.l + j_m;
+        q = c.t - i_m;
+    } else {
+        p = c.l + j * c.pix_width;
+        q = c.t - i * c.pix_width;
+    }
+    r = -c.d;
+    d3 d = unit3(add3(add3(scale3(p, u), scale3(q, v)), scale3(r, w)));
+    d3 o = e;
+    if (P.aperture > 0) {
+        d3 uOff = scale3(P.aperture, scale3(normed_rand(gpix, sample, 2, P.seed) - .5, u));
+        d3 vOff = scale3(P.aperture, scale3(normed_rand(gpix, sample, 3, P.seed) - .5, v));
+        o = add3(o, add3(uOff, vOff));
+        p = c.l + j * c.pix_width;
+        q = c.t - i * c.pix_width;
+        d3 focus = add3(add3(add3(scale3(p, u), scale3(q, v)), scale3(r, w)), e);
+        d = unit3(sub3(focus, o));
+    }
+    *o_out = o;
+    *d_out = d;
+}
+
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
 template <bool PRIMARY, bool BVH>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams P, QueueSet Q)
 {
+#define STAMP_SEL (Q.generation)
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k * block size + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
     const int lane = (int)(threadIdx.x & 63);
+    STAMP(0);
     ShardMap smap;
     smap.items = smap.first = smap.total = 0;
     if (!PRIMARY) smap = shard_map(&Q.counts[CNT_RAYS(Q.generation)], Q.in_shard_cap, 1u);
@@ -31,16 +122,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
     // a block none of whose waves gets a chunk leaves before it copies anything into LDS (late
     // generations of small frames fill only a few of the launched blocks)
     if ((long long)blockIdx.x * (blockDim.x >> 6) >= n_chunks) return;
-    if (PRIMARY && threadIdx.x == 0) {
-        // The camera's 16 doubles go to LDS once per block and are read back per chunk.  As kernel
-        // arguments they would occupy 32 scalar registers for the whole kernel; the scalar file is
-        // already over-subscribed by the scene's pointers, and every value spilled from it costs a
-        // vector instruction each time it is brought back (a seventh of this kernel's vector work).
-        double *cw = reinterpret_cast<double *>(&s_lds[P.S.lds_cam_word]);
-        for (int k = 0; k < 3; ++k) { cw[k] = P.cam.u[k]; cw[3 + k] = P.cam.v[k]; cw[6 + k] = P.cam.w[k]; cw[9 + k] = P.cam.e[k]; }
-        cw[12] = P.cam.d; cw[13] = P.cam.l; cw[14] = P.cam.t; cw[15] = P.cam.pix_width;
-    }
+    if (PRIMARY && threadIdx.x == 0) camera_to_lds(P);
+    STAMP(1);
     fill_node_cache(P.S, BVH);      // ends with the block's barrier
+    STAMP(2);
     const bool cull = P.cull_closest != 0;
     WalkCount wc{};
 
@@ -51,74 +136,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
         uint32_t pixel = 0, meta = 5u | 0x100u;
         bool first_sample = false;
         if (PRIMARY) {
-            // Primary ordering: pixels in 8x8 blocks (row-major inside a block), the N*N samples of a
-            // pixel in consecutive positions; a wave takes 64 consecutive positions.
-            // Positions are counted from the batch's first block, which keeps them in 32 bits, and every
-            // division is by a number fixed for the launch (a multiplication, see FastDiv).
-            const int N = P.N;
-            const uint32_t rel = (uint32_t)chunk * 64u + (uint32_t)lane;
-            const uint32_t spp = (uint32_t)(N * N);
-            const uint32_t pseq = fast_div(rel, P.div_spp);              // pixel, counted from the batch's first
-            const int smp = (int)(rel - pseq * spp);
-            const int within = (int)(pseq & 63u);
-            const uint32_t col = (uint32_t)Q.block_col0 + (pseq >> 6);   // block column, not yet wrapped into the row
-            const uint32_t wraps = fast_div(col, P.div_blocks_x);
-            const int bx = (int)(col - wraps * (uint32_t)P.blocks_x);
-            const long long by = Q.block_row0 + wraps;
-            const int j = bx * 8 + (within & 7);
-            const long long lrow_ll = by * 8 + (within >> 3);
-            const int lrow = lrow_ll < P.local_rows ? (int)lrow_ll : P.local_rows;     // beyond the part: inactive below
-            const int si = (int)fast_div((uint32_t)smp, P.div_n), sj = smp - si * N;
-            active = j < P.cam.resx && lrow < P.local_rows;
-            const int i = global_row(P, lrow);
-            pixel = (uint32_t)lrow * (uint32_t)P.cam.resx + (uint32_t)j;
-            first_sample = (si == 0 && sj == 0);
-            struct { double d, l, t, pix_width; int resx; } c;
-            d3 u, v, w, e;
-            {
-                typedef double v2d __attribute__((ext_vector_type(2)));
-                const __attribute__((address_space(3))) v2d *cw =
-                    (const __attribute__((address_space(3))) v2d *)((__attribute__((address_space(3))) const int *)s_lds + P.S.lds_cam_word);
-                const v2d c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3], c4 = cw[4], c5 = cw[5], c6 = cw[6], c7 = cw[7];
-                u = mk3(c0.x, c0.y, c1.x); v = mk3(c1.y, c2.x, c2.y); w = mk3(c3.x, c3.y, c4.x); e = mk3(c4.y, c5.x, c5.y);
-                c.d = c6.x; c.l = c6.y; c.t = c7.x; c.pix_width = c7.y;
-                c.resx = P.cam.resx;
-            }
-            const uint32_t gpix = (uint32_t)i * (uint32_t)c.resx + (uint32_t)j;
-            const uint32_t sample = (uint32_t)(si * N + sj);
-            double p, q, r;
-            if (N > 1) {
-                double spw = c.pix_width / N;
-                double randX = normed_rand(gpix, sample, 0, P.seed);
-                double randY = normed_rand(gpix, sample, 1, P.seed);
-                randX -= .5;
-                randY -= .5;
-                double edgeX = (j - .5) * c.pix_width;
-                double edgeY = (i - .5) * c.pix_width;
-                double j_m = edgeX + sj * spw + .5 * spw;
-                double i_m = edgeY + si * spw + .5 * spw;
-                randX *= spw;
-                randY *= spw;
-                j_m += randX;
-                i_m += randY;
-                p = c.l + j_m;
-                q = c.t - i_m;
-            } else {
-                p = c.l + j * c.pix_width;
-                q = c.t - i * c.pix_width;
-            }
-            r = -c.d;
-            d = unit3(add3(add3(scale3(p, u), scale3(q, v)), scale3(r, w)));
-            o = e;
-            if (P.aperture > 0) {
-                d3 uOff = scale3(P.aperture, scale3(normed_rand(gpix, sample, 2, P.seed) - .5, u));
-                d3 vOff = scale3(P.aperture, scale3(normed_rand(gpix, sample, 3, P.seed) - .5, v));
-                o = add3(o, add3(uOff, vOff));
-                p = c.l + j * c.pix_width;
-                q = c.t - i * c.pix_width;
-                d3 focus = add3(add3(add3(scale3(p, u), scale3(q, v)), scale3(r, w)), e);
-                d = unit3(sub3(focus, o));
-            }
+            primary_ray(P, Q, chunk, lane, &active, &o, &d, &pixel, &first_sample);
         } else {
             int shard;
             const int local = shard_locate(smap, (uint32_t)chunk, &shard);
@@ -135,6 +153,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
 
         double best_t = 0;
         int best = -1, best_prim = -1;
+        STAMP(3);
         if (active) {
             if (BVH) {
                 const double d2 = dot3(d, d);
@@ -156,6 +175,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
         const rt_tri_rec *tri_arr = BVH ? P.S.btri : P.S.tri;
         const rt_sph_rec *sph_arr = BVH ? P.S.bsph : P.S.sph;
         const uint32_t *sph_prim_arr = BVH ? P.S.bsph_prim : P.S.sph_prim;
+        STAMP(4);
 
         const bool first = (meta & 0x100u) != 0;
         const int L = (int)(meta & 0xffu);
@@ -176,7 +196,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
         if (PRIMARY && active && first_sample && P.hit_id) P.hit_id[pixel] = prim;
         // misses add the background (placed after the hit's table fetches have been issued, so that their
         // latency runs beside the shuffles and atomics of this sum)
+        STAMP(5);
         accum_add_runs(P.accum, active, active && !hit, pixel, wloc, ld3(P.S.bg));
+        STAMP(6);
 
         // Queue pushes.  The three reservations (hit record, refraction ray, reflection ray) are made
         // with two atomics -- both kinds of ray go to the same queue -- issued back to back by one lane,
@@ -196,6 +218,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
         }
         base_h = (uint32_t)__shfl((int)base_h, 0);
         base_r = (uint32_t)__shfl((int)base_r, 0);
+        STAMP(7);
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t slot_h = base_h + (uint32_t)__popcll(mask_h & below);
         const uint32_t slot_a = base_r + (uint32_t)__popcll(mask_a & below);
@@ -231,10 +254,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
                                   rec_pack_words(pixel, (uint32_t)(L - 1), 0u, 0u)};
             rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_b], q);
         }
+        STAMP(8);
     }
+    STAMP(9);
 #ifdef RT_COUNT
     walk_count_flush(wc, PRIMARY ? 0 : 8);
 #endif
+#undef STAMP_SEL
 }
 
 
@@ -252,16 +278,20 @@ template <int MODE>
 DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
 {
     constexpr bool BVH = MODE != SHADOW_EXACT;      // the hierarchies (and their LDS stacks and node cache) are in use
+#define STAMP_SEL (8 + Q.generation)
 #ifdef RT_COUNT
     const long long t_begin = wall_clock64();
 #endif
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k * block size + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
     const uint32_t nl = (uint32_t)P.S.n_lights;
+    STAMP(0);
     // work items are (hit, light) pairs, the lights of one hit in consecutive items
     const ShardMap smap = shard_map(&Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, nl);
     if ((long long)blockIdx.x * (blockDim.x >> 6) >= (long long)smap.total) return;   // no chunk for this block
+    STAMP(1);
     fill_node_cache(P.S, BVH);
+    STAMP(2);
     const bool cull = P.cull_shadow != 0;
     WalkCount wc{};
     for (long long chunk = next_chunk(P.S); chunk < (long long)smap.total; chunk = next_chunk(P.S)) {
@@ -282,6 +312,7 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
         bool lit = false;
         int defer_cam = -1;
         d3 local = mk3(0, 0, 0);
+        STAMP(3);
         if (active) {
             const d3 toL = sub3(lpos, Pt);
             const d3 rd = unit3(toL);
@@ -323,6 +354,7 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
                 }
             }
             lit = !occluded;
+            STAMP(4);
             if (lit) {
                 const rt_light lgt = load_light(P.S, li, true);     // read again here rather than kept in registers through the walk
                 // the view vector from the record; the two normals from the record too, or from the primitive's table
@@ -357,14 +389,18 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
                 }
             }
         }
+        STAMP(5);
         accum_add_runs(P.accum, active, lit, pixel, weight, local);
+        STAMP(8);
     }
+    STAMP(9);
 #ifdef RT_COUNT
     walk_count_flush(wc, 16);
     // lifetime of the wave in 100 MHz ticks: summed over a launch and set against its duration it tells how full
     // the resident wave slots were (tools/exp_tail.py)
     if ((threadIdx.x & 63) == 0) atomicAdd(&g_walk_counts[40], (unsigned long long)(wall_clock64() - t_begin));
 #endif
+#undef STAMP_SEL
 }
 
 template <bool BVH>
@@ -375,6 +411,276 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_shadow(FrameP
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_shadow_hybrid(FrameParams P, QueueSet Q)
 {
     shadow_pass<SHADOW_HYBRID>(P, Q);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The whole ray tree of a sample in one launch, for frames too small to fill the chip pass by pass.
+//
+// The wavefront pipeline above spends a launch per generation and kind of ray; a frame of a few hundred thousand
+// samples fills the chip once at most, so each of its twelve passes lasts as long as one wave's walk plus what every
+// pass pays again (LDS fill, queue counters, record round trips through memory, ramp and tail).  Here a lane keeps
+// its sample from the primary ray to the last secondary ray: closest hit, the shadow queries of that hit towards
+// every light, then the next ray of the tree (Camera.h:232-314 unrolled depth first: the refraction ray continues in
+// registers, the reflection ray of the same hit waits in a small per-lane stack in private memory).  Nothing goes
+// through queues except the deferred light-camera queries, the sample's colour is summed in registers and added to
+// the accumulation frame once.  Lanes whose tree has ended idle until the wave's longest tree is done: acceptable
+// exactly when there are not enough samples to fill the idle lanes anyway, so large frames keep the wavefront path.
+struct PendingRay {          // a ray of the tree that waits for its turn
+    double o[3], d[3], A, coef;
+    uint32_t meta, _pad;
+};
+#define FUSED_PENDING 6      // a hit spawns at most two rays, one of which continues at once: at most one entry per level
+#ifndef RT_MIN_WAVES_FUSED
+#define RT_MIN_WAVES_FUSED 1
+#endif
+template <bool BVH, int MODE>
+__global__ __launch_bounds__(256, RT_MIN_WAVES_FUSED) void k_fused(FrameParams P, QueueSet Q)
+{
+#define STAMP_SEL 16
+    int *stack = &s_lds[BVH ? threadIdx.x : 0];
+    const int lane = (int)(threadIdx.x & 63);
+    const long long n_chunks = Q.chunk_end - Q.chunk_begin;
+    if ((long long)blockIdx.x * (blockDim.x >> 6) >= n_chunks) return;
+    STAMP(0);
+    if (threadIdx.x == 0) camera_to_lds(P);
+    fill_node_cache(P.S, BVH);
+    STAMP(2);
+    const bool cull = P.cull_closest != 0, cull_sh = P.cull_shadow != 0;
+    const int nl = P.S.n_lights;
+    WalkCount wc{};
+    // rays and hits per generation, counted per wave (generation 0's rays are the samples: the host knows them)
+    unsigned int w_rays[6] = {0, 0, 0, 0, 0, 0}, w_hits[6] = {0, 0, 0, 0, 0, 0};
+
+    for (long long chunk = next_chunk(P.S); chunk < n_chunks; chunk = next_chunk(P.S)) {
+        bool active, first_sample;
+        d3 o, d;
+        uint32_t pixel;
+        primary_ray(P, Q, chunk, lane, &active, &o, &d, &pixel, &first_sample);
+        double A = 1.0, coef = 1.0;
+        uint32_t meta = 5u | 0x100u;
+        bool have = active, primary = true;
+        d3 sum = mk3(0, 0, 0);
+        PendingRay pend[FUSED_PENDING];
+        int sp = 0;
+#ifdef RT_STAMP
+        int stamp_iter = 0;
+#endif
+        while (__ballot(have) != 0) {
+            const int L = (int)(meta & 0xffu);
+#ifdef RT_STAMP
+            if (stamp_iter == 0) STAMP(3);
+            if (stamp_iter == 1) STAMP(4);
+            if (stamp_iter == 2) STAMP(9);
+            ++stamp_iter;
+#define STAMP_IT(k) do { if (stamp_iter == 2) STAMP(k); } while (0)
+#else
+#define STAMP_IT(k) ((void)0)
+#endif
+            // ---- closest hit (Camera.h:318-363)
+            double best_t = 0;
+            int best = -1, best_prim = -1;
+            if (have) {
+                if (BVH) {
+                    const double d2 = dot3(d, d);
+                    Best bst;
+                    bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1; bst.prim = -1;
+                    if (root_gate(P.S, o, d, d2, 10000000000.0)) {
+                        const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
+                        bvh_closest<true>(P.S, o, d, d2, rb, bst, stack, wc);
+                        bvh_closest<false>(P.S, o, d, d2, rb, bst, stack, wc);
+                    }
+                    best_t = bst.t; best = bst.slot; best_prim = bst.prim;
+                } else {
+                    trace_closest(P.S, o, d, cull, .01, best_t, best);
+                }
+            }
+            STAMP_IT(5);
+            const rt_tri_rec *tri_arr = BVH ? P.S.btri : P.S.tri;
+            const rt_sph_rec *sph_arr = BVH ? P.S.bsph : P.S.sph;
+            const uint32_t *sph_prim_arr = BVH ? P.S.bsph_prim : P.S.sph_prim;
+            const bool first = (meta & 0x100u) != 0;
+            const double wloc = first ? A : A * coef;
+            const bool hit = have && best >= 0;
+            d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0);
+            int prim = -1, mat = 0;
+            bool flat = false;
+            rt_material m;
+            m.Ks = 0; m.T = 0; m.ior = 1;
+            if (hit) {
+                hit_geometry(P.S, tri_arr, sph_arr, sph_prim_arr, P.flags, o, d, .01, best_t, best, best_prim, &prim, &n, &Pt, &flat);
+                mat = P.S.prim_material[prim];
+                m = load_material(P.S, mat, true);
+            }
+            if (primary && active && first_sample && P.hit_id) P.hit_id[pixel] = prim;
+            if (have && !hit) {      // a miss adds the background
+                const d3 bg = ld3(P.S.bg);
+                sum = add3(sum, mk3(wloc * bg.x, wloc * bg.y, wloc * bg.z));
+            }
+            const bool want_hit = hit && nl > 0;
+            // per-generation counts of the wave (uniform values: ballots and scalar adds)
+            {
+                const int gen = 5 - L;
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {
+                    if (g > 0) w_rays[g] += (unsigned int)__popcll(__ballot(have && gen == g));
+                    w_hits[g] += (unsigned int)__popcll(__ballot(want_hit && gen == g));
+                }
+            }
+
+            STAMP_IT(6);
+            // ---- the lights of this hit (Camera.h:385-485)
+            if (__ballot(want_hit) != 0) {
+                d3 vv = mk3(0, 0, 0), n2 = mk3(0, 0, 0), n3 = mk3(0, 0, 0);
+                if (want_hit) {
+                    vv = unit3(sub3(o, Pt));
+                    if (!flat) { n2 = unit3(n); n3 = unit3(n2); }
+                }
+                for (int li = 0; li < nl; ++li) {
+                    const d3 lpos = ld3(load_light(P.S, li, true).pos);
+                    bool lit = false;
+                    int defer_cam = -1;
+                    d3 local = mk3(0, 0, 0);
+                    if (want_hit) {
+                        const d3 toL = sub3(lpos, Pt);
+                        const d3 rd = unit3(toL);
+                        const double maxT = norm3(toL) - .01;
+                        bool only = false;
+                        int closest = -1;
+                        bool occluded;
+                        bool order_free = MODE == SHADOW_BVH;
+                        if (MODE == SHADOW_HYBRID) {
+                            const double d2 = dot3(rd, rd);
+                            order_free = true;
+                            for (int k = 0; k < P.S.n_tsph; ++k)
+                                if (P.S.tsph_prim[k] != prim && sph_test(&P.S.tsph[k], Pt, rd, d2, .01, maxT) < maxT) order_free = false;
+                        }
+                        if (order_free) {
+                            const double d2 = dot3(rd, rd);
+                            occluded = false;
+                            if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
+                                const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
+                                occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, prim, maxT, stack, wc) ||
+                                           bvh_any<false>(P.S, Pt, rd, d2, rb, prim, maxT, stack, wc);
+                            }
+                        } else if (MODE != SHADOW_BVH) {
+                            occluded = trace_shadow(P.S, Pt, rd, prim, maxT, cull_sh, &only, &closest);
+                        } else {
+                            occluded = false;
+                        }
+                        if (occluded && only) {
+                            if (P.lc_mask) P.lc_mask[pixel] = 1;
+                            if (P.S.lc_table && closest >= 0) {
+                                const int rank = P.S.prim_lc_rank[closest];
+                                if (rank >= 0) defer_cam = rank * nl + li;
+                            }
+                        }
+                        lit = !occluded;
+                        if (lit) {
+                            const rt_light lgt = load_light(P.S, li, true);
+                            d3 na = n2, nb = n3;
+                            if (flat) {
+                                const void *nsrc = (const void *)&P.S.prim_n23[(size_t)prim * 6];
+                                const rec_v2d q0 = rec_load(nsrc, 0), q1 = rec_load(nsrc, 1), q2 = rec_load(nsrc, 2);
+                                na = mk3(q0.x, q0.y, q1.x); nb = mk3(q1.y, q2.x, q2.y);
+                            }
+                            local = phong_terms(load_material(P.S, mat, true), na, nb, vv, &lgt, rd, .999999);
+                        }
+                    }
+                    if (MODE != SHADOW_BVH && P.S.lc_table) {
+                        // the light camera decides (Camera.h:406-451): postponed to k_lightcam, which runs such queries in full waves
+                        bool ok;
+                        const bool want = defer_cam >= 0;
+                        const uint32_t slot = wave_reserve(want, &Q.counts[CNT_DEFER(0)], Q.hit_shard_cap, &Q.counts[CNT_OVERFLOW + 1], &ok);
+                        if (ok) {
+                            HitRec *dr = &Q.deferred[slot];
+                            const rec_v2d q[4] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, vv.x), rec_pack(vv.y, vv.z),
+                                                  rec_pack(wloc, __hiloint2double(prim, (int)(pixel | (flat ? HIT_FLAT : 0u))))};
+                            rec_store(dr, q);
+                            const rec_v2d r[4] = {rec_pack_words((uint32_t)li, (uint32_t)defer_cam, (uint32_t)mat, 0u), rec_pack(n2.x, n2.y),
+                                                  rec_pack(n2.z, n3.x), rec_pack(n3.y, n3.z)};
+                            rec_store(&dr->light, r);
+                        } else if (want) {   // queue full: evaluate here
+                            const double kfac = lc_calc_intensity(P.S.lc_table, defer_cam, Pt);
+                            if (kfac > .01) {
+                                lit = true;
+                                const rt_light lgt = load_light(P.S, li, true);
+                                d3 na = n2, nb = n3;
+                                if (flat) { na = ld3(&P.S.prim_n23[(size_t)prim * 6]); nb = ld3(&P.S.prim_n23[(size_t)prim * 6 + 3]); }
+                                local = phong_terms(load_material(P.S, mat, true), na, nb, vv, &lgt, unit3(sub3(lpos, Pt)), kfac);
+                            }
+                        }
+                    }
+                    if (lit) sum = add3(sum, mk3(wloc * local.x, wloc * local.y, wloc * local.z));
+                }
+            }
+
+            STAMP_IT(7);
+            // ---- the next ray of this sample's tree (Camera.h:244-307)
+            const bool spawn = hit && L > 0 && !(coef < .01);
+            const double coef2 = coef * m.Ks;
+            const bool want_refr = spawn && m.T > 0;
+            const bool want_refl = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
+            bool cont = false;
+            d3 nd = d;
+            double nA = A, ncoef = coef;
+            uint32_t nmeta = meta;
+            if (want_refl) {
+                nd = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));      // hr.reflectionDir (Solid.h:121-122)
+                ncoef = coef2;
+                nmeta = (uint32_t)(L - 1);
+                cont = true;
+            }
+            if (want_refr) {
+                if (cont) {
+                    if (sp < FUSED_PENDING) {
+                        PendingRay &pr = pend[sp];
+                        pr.o[0] = Pt.x; pr.o[1] = Pt.y; pr.o[2] = Pt.z;
+                        pr.d[0] = nd.x; pr.d[1] = nd.y; pr.d[2] = nd.z;
+                        pr.A = nA; pr.coef = ncoef; pr.meta = nmeta;
+                        ++sp;
+                    } else {
+                        Q.counts[CNT_OVERFLOW] = 1u;      // cannot happen (one entry per level); reported if it does
+                    }
+                }
+                nd = refract_dir(d, n, m.ior, false);
+                nA = A * m.T;
+                ncoef = m.T * coef;
+                nmeta = (uint32_t)(L - 1) | 0x100u;
+                cont = true;
+            }
+            d3 no = Pt;
+            if (have && !cont && sp > 0) {
+                --sp;
+                const PendingRay &pr = pend[sp];
+                no = ld3(pr.o); nd = ld3(pr.d);
+                nA = pr.A; ncoef = pr.coef; nmeta = pr.meta;
+                cont = true;
+            }
+            have = have && cont;
+            o = no; d = nd; A = nA; coef = ncoef; meta = nmeta;
+            primary = false;
+        }
+        STAMP(10);
+        accum_add_runs(P.accum, active, true, pixel, 1.0, sum);
+    }
+    STAMP(11);
+    // totals: [0] closest rays, [1] shadow rays, [2+g] rays and [8+g] hits of generation g, [15] overflow
+    if (lane == 0) {
+        unsigned long long r = 0, h = 0;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            if (w_rays[g]) atomicAdd(&Q.totals[2 + g], (unsigned long long)w_rays[g]);
+            if (w_hits[g]) atomicAdd(&Q.totals[8 + g], (unsigned long long)w_hits[g]);
+            r += w_rays[g]; h += w_hits[g];
+        }
+        if (r) atomicAdd(&Q.totals[0], r);
+        if (h) atomicAdd(&Q.totals[1], h * (unsigned long long)nl);
+    }
+#ifdef RT_COUNT
+    walk_count_flush(wc, 0);
+#endif
+#undef STAMP_SEL
 }
 
 // Deferred light-camera evaluations of a batch, all six generations in one launch: density query,

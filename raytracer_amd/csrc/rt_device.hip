@@ -65,6 +65,8 @@ void *g_scratch_ptr[RT_MAX_DEVICES] = {};       // per device: address of that d
 
 // Queue memory one context may take unless rt_set_memory_budget says otherwise.
 #define RT_DEFAULT_QUEUE_BUDGET ((size_t)96 << 30)
+// Frames of at most this many samples run as one launch per batch (k_fused) instead of the wavefront pipeline.
+#define RT_FUSED_MAX_SAMPLES (1ll << 20)
 
 // Experiment switches (rt_debug_set_option); the defaults are what the product runs.
 struct DebugOptions {
@@ -74,6 +76,7 @@ struct DebugOptions {
     int rounds = 0;                 // rounds of resident blocks a queued pass is cut into (default 2)
     bool verbose = false;           // device properties, light-camera and splitter statistics on stderr
     int leaf_max = 0, split_budget = -1;   // hierarchy builder (accel::Options), read at the next upload
+    int fused = -1;                 // 1: always the one-launch kernel, 0: never, -1: by frame size
 };
 
 // ------------------------------------------------------------------ host side
@@ -86,6 +89,7 @@ struct rt_ctx {
     std::vector<void *> scene_allocs;
     bool has_scene = false;
     bool any_transparent = false;          // any material with T > 0
+    bool any_secondary = false;            // any material with Ks != 0 or T > 0: ray trees go beyond the first hit
     bool any_transparent_sphere = false;
     bool any_sphere = false, any_vnormals = false;
     bool spheres_inside_root = true;       // every sphere lies inside the root cube
@@ -117,6 +121,7 @@ struct rt_ctx {
     DebugOptions dbg;
     // pending async frame
     unsigned long long *pending_totals = nullptr;
+    bool pending_fused = false;            // the frame in flight ran as k_fused launches
     bool pending = false;
     uint32_t pending_flags = 0;
     unsigned long long pending_primaries = 0;
@@ -199,7 +204,9 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
         const int lds_max = (int)ctx->lds_per_cu;
         const void *kernels[] = {(const void *)k_closest<true, true>,  (const void *)k_closest<true, false>, (const void *)k_closest<false, true>,
                                  (const void *)k_closest<false, false>, (const void *)k_shadow<true>,       (const void *)k_shadow<false>,
-                                 (const void *)k_shadow_hybrid};
+                                 (const void *)k_shadow_hybrid,
+                                 (const void *)k_fused<true, SHADOW_BVH>, (const void *)k_fused<true, SHADOW_HYBRID>,
+                                 (const void *)k_fused<true, SHADOW_EXACT>, (const void *)k_fused<false, SHADOW_EXACT>};
         for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     }
     if (device_id < RT_MAX_DEVICES) {
@@ -279,6 +286,25 @@ extern "C" int rt_debug_counters(unsigned long long *out48)
     HIP_TRY(hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_walk_counts), 48 * sizeof(unsigned long long)));
     unsigned long long zero[48] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_counts), zero, sizeof zero));
+    return RT_OK;
+}
+#endif
+
+#ifdef RT_STAMP
+// Diagnostic builds: the clock stamps (100 MHz ticks) the waves of the last traversal launches left; cleared by the call.
+extern "C" int rt_debug_stamp_select(int kind_times_8_plus_generation)
+{
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_select), &kind_times_8_plus_generation, sizeof(int)));
+    return RT_OK;
+}
+extern "C" int rt_debug_stamps(unsigned long long *out, int n_words)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t bytes = sizeof(unsigned long long) * (size_t)(n_words < RT_STAMP_WAVES * RT_STAMP_SLOTS ? n_words : RT_STAMP_WAVES * RT_STAMP_SLOTS);
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), bytes));
+    void *p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)));
+    HIP_TRY(hipMemset(p, 0, sizeof(unsigned long long) * RT_STAMP_WAVES * RT_STAMP_SLOTS));
     return RT_OK;
 }
 #endif
@@ -416,7 +442,11 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     ctx->lightcam_samples = s->lightcam_samples;
     ctx->n_materials = s->n_materials;
     ctx->any_transparent = false;
-    for (int32_t i = 0; i < s->n_materials; ++i) if (s->materials[i].T > 0) ctx->any_transparent = true;
+    ctx->any_secondary = false;
+    for (int32_t i = 0; i < s->n_materials; ++i) {
+        if (s->materials[i].T > 0) ctx->any_transparent = true;
+        if (s->materials[i].T > 0 || s->materials[i].Ks != 0.0) ctx->any_secondary = true;
+    }
     ctx->any_sphere = s->n_sph_slots > 0;
     ctx->any_vnormals = false;
     for (int32_t p = 0; p < s->n_prims; ++p) if (s->prim_flags[p] & RT_PRIM_HAS_VNORMALS) ctx->any_vnormals = true;
@@ -874,8 +904,17 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     if (stack_entries < 4) stack_entries = 4;
     // Block size.  Large batches run one 1024-thread block per compute unit (one LDS copy of the top of the scene
     // per compute unit); small ones, which live on latency and on many independent blocks, 256-thread blocks.
-    int block = (noalloc || batch_chunks * 64 <= (1ll << 22)) ? 256 : RT_BLOCK;
-    if (ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024) block = ctx->dbg.block_threads;
+    // The one-launch kernel (k_fused: a lane follows its sample's whole tree) is chosen for frames that cannot fill the
+    // chip pass by pass AND whose trees end at the first hit -- no material reflects or refracts.  Measured at 512x512:
+    // tetra-3 0.249 -> 0.063 ms.  With deeper trees a wave lasts as long as its deepest sample (six generations of
+    // closest hit plus shadow queries, each a whole walk long), which is what the wavefront pipeline's passes also add
+    // up to, and the regrouping of the survivors into full waves is lost: teapot-3 0.40 -> 0.38 ms, refract 0.47 -> 0.45,
+    // balls 0.69 -> 0.86.  The "fused" option forces either path.
+    const bool use_fused = !noalloc && local_rows > 0 &&
+                           (ctx->dbg.fused == 1 || (ctx->dbg.fused < 0 && (long long)n_pixels * spp <= RT_FUSED_MAX_SAMPLES &&
+                                                    !ctx->any_secondary && !(o->flags & RT_FLAG_KEEP_ZERO_WEIGHT)));
+    int block = (noalloc || use_fused || batch_chunks * 64 <= (1ll << 22)) ? 256 : RT_BLOCK;
+    if (!use_fused && (ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024)) block = ctx->dbg.block_threads;
     const int blocks_per_cu = 1024 / block, waves_per_block = block / 64;
     P.S.stack_shift = block == 256 ? 8 : 10;
     // LDS per block: the stacks, the material and light tables, then as many top-of-tree nodes as fit
@@ -939,7 +978,25 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     QueuePlan QP;
     FrameBuffers B;
     bool overlap = false;
-    if (local_rows > 0 && !noalloc) {
+    long long fused_defer_cap = 0;
+    if (use_fused) {
+        // no ray or hit queues; only the deferred light-camera queries leave the kernel (when that queue is full they are
+        // answered in place, so its size is a matter of speed, not of correctness)
+        if (batch_chunks > (1ll << 25) / spp * spp) batch_chunks = (1ll << 25) / spp * spp;
+        if (batch_chunks < spp) batch_chunks = spp;
+        int rc;
+        if ((rc = ensure(&ctx->accum, &ctx->accum_values, n_pixels * 3)) != RT_OK) return rc;
+        if (use_lightcam) {
+            const long long bs = batch_chunks < n_chunks ? batch_chunks : n_chunks;
+            fused_defer_cap = (bs * 64 * 2 + N_SHARDS - 1) / N_SHARDS;
+            if (fused_defer_cap < 1024) fused_defer_cap = 1024;
+            if ((rc = ensure(&ctx->deferred[0], &ctx->deferred_capacity[0], (size_t)(fused_defer_cap * N_SHARDS))) != RT_OK) return rc;
+        }
+        B.accum = ctx->accum;
+        B.deferred[0] = ctx->deferred[0];
+        B.counts = ctx->counts;
+        B.totals = ctx->totals;
+    } else if (local_rows > 0 && !noalloc) {
         // Overlap pays when a pass cannot fill the chip by itself (small frames: each pass is one
         // ray's latency long); big batches already saturate it with one persistent grid, and there
         // the extra ordering constraints only cost, so they run on one stream.
@@ -1011,6 +1068,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     ctx->pending_batches = 0;
     ctx->pending_primaries = (unsigned long long)n_pixels * (unsigned long long)(N * N);
     ctx->pending_totals = B.totals;
+    ctx->pending_fused = use_fused;
 
     if (local_rows > 0) {
         HIP_TRY(hipMemsetAsync(B.accum, 0, n_pixels * 3 * sizeof(double), st));
@@ -1045,6 +1103,52 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         hipStream_t sb = overlap ? ctx->stream2 : st;
         const bool timing = (o->flags & RT_FLAG_TIMING) != 0;
         long long batch_no = 0;
+        if (use_fused) {
+            const void *kfn = !bvh_closest_ok ? (const void *)k_fused<false, SHADOW_EXACT>
+                              : bvh_shadow_ok ? (const void *)k_fused<true, SHADOW_BVH>
+                              : hybrid_shadow ? (const void *)k_fused<true, SHADOW_HYBRID>
+                                              : (const void *)k_fused<true, SHADOW_EXACT>;
+            int resident = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kfn, 256, lds_bvh));
+            if (resident < 1) resident = 1;
+            if (resident > 8) resident = 8;
+            for (long long t0 = 0; t0 < n_chunks; t0 += batch_chunks, ++batch_no) {
+                const long long t1 = (t0 + batch_chunks < n_chunks) ? t0 + batch_chunks : n_chunks;
+                uint32_t *counts = B.counts;
+                HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
+                QueueSet Q{};
+                Q.deferred = B.deferred[0];
+                Q.counts = counts;
+                Q.hit_shard_cap = (uint32_t)fused_defer_cap;
+                Q.generation = 0;
+                Q.chunk_begin = t0;
+                Q.chunk_end = t1;
+                Q.block_row0 = (t0 / (N * N)) / P.blocks_x;
+                Q.block_col0 = (int32_t)((t0 / (N * N)) % P.blocks_x);
+                Q.totals = B.totals;
+                long long blocks = (t1 - t0 + 3) / 4;
+                if (blocks > (long long)ctx->cu_count * resident) blocks = (long long)ctx->cu_count * resident;
+                std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+                if (timing && !(ev = next_event_pair(ctx->ev_closest, ctx->ev_closest_used)))
+                    return fail(RT_ERR_DEVICE, "hipEventCreate failed");
+                if (ev) HIP_TRY(hipEventRecord(ev->first, st));
+                if (!bvh_closest_ok) hipLaunchKernelGGL((k_fused<false, SHADOW_EXACT>), dim3((unsigned)blocks), dim3(256), lds_bvh, st, P, Q);
+                else if (bvh_shadow_ok) hipLaunchKernelGGL((k_fused<true, SHADOW_BVH>), dim3((unsigned)blocks), dim3(256), lds_bvh, st, P, Q);
+                else if (hybrid_shadow) hipLaunchKernelGGL((k_fused<true, SHADOW_HYBRID>), dim3((unsigned)blocks), dim3(256), lds_bvh, st, P, Q);
+                else hipLaunchKernelGGL((k_fused<true, SHADOW_EXACT>), dim3((unsigned)blocks), dim3(256), lds_bvh, st, P, Q);
+                if (ev) HIP_TRY(hipEventRecord(ev->second, st));
+                if (use_lightcam) {
+                    LightcamQueues L{};
+                    L.deferred[0] = B.deferred[0];
+                    L.shard_cap[0] = (uint32_t)fused_defer_cap;
+                    L.counts = counts;
+                    hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks_256), dim3(256), 0, st, P, L);
+                }
+                hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, counts, B.totals, P.S.n_lights);
+                ctx->pending_batches++;
+            }
+            HIP_TRY(hipEventRecord(ctx->ev_batch[0], st));
+        } else
         for (long long t0 = 0; t0 < n_chunks; t0 += batch_chunks, ++batch_no) {
             const long long t1 = (t0 + batch_chunks < n_chunks) ? t0 + batch_chunks : n_chunks;
             const int par = (int)(batch_no & 1);
@@ -1110,7 +1214,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         }
         // the frame is complete when the second stream has drained
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[0], 0));
-        if (batch_no >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[1], 0));
+        if (batch_no >= 2 && !use_fused) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[1], 0));
         HIP_TRY(hipGetLastError());
         {
             const long long n_values = (long long)n_pixels * 3;
@@ -1159,7 +1263,7 @@ extern "C" int rt_sync(rt_ctx *ctx, rt_stats *stats)
                 float m = 0;
                 HIP_TRY(hipEventElapsedTime(&m, ctx->ev_closest[i].first, ctx->ev_closest[i].second));
                 c += m;
-                if (i % 6 == 0) { prim += m; ++prim_n; }      // six closest-hit passes per batch, generation 0 first
+                if (ctx->pending_fused || i % 6 == 0) { prim += m; ++prim_n; }      // six closest-hit passes per batch, generation 0 first
             }
             stats->primary_ms = prim;
             stats->primary_launches = prim_n;
@@ -1245,6 +1349,7 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "verbose") ctx->dbg.verbose = value != 0;
     else if (n == "leaf_max") ctx->dbg.leaf_max = (int)value;
     else if (n == "split_budget") ctx->dbg.split_budget = (int)value;
+    else if (n == "fused") ctx->dbg.fused = (int)value;
     else if (n == "queue_growth") ctx->growth = value < 1 ? 1 : (value > 32 ? 32 : (int)value);
     else return fail(RT_ERR_INVALID, "rt_debug_set_option: unknown option '" + n + "'");
     return RT_OK;

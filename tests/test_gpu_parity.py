@@ -225,6 +225,46 @@ def test_small_batches_equal_one_batch(gpu):
     assert a["stats"]["shadow_rays"] == b["stats"]["shadow_rays"]
 
 
+@pytest.mark.parametrize("scene,res,kw", [
+    ("tetra-3", None, {}), ("teapot-3", None, {}), ("balls", (256, 256), {}), ("refract", (256, 256), {}),
+    ("gears", (128, 128), {}), ("teapot-3", (100, 90), {"num_samples": 3, "aperture": 0.2, "seed": 5}),
+    ("teapot-3", None, {"phong": True})])
+def test_one_launch_kernel_equals_oracle(gpu, oracle_frame, scene, res, kw):
+    """The kernel that follows a sample's whole ray tree in one launch (chosen by itself only for small frames of scenes
+    whose materials neither reflect nor refract) forced on scenes of every kind: same bar as the wavefront pipeline."""
+    s = load_scene(gpu, scene)
+    phong = kw.pop("phong", False)
+    gpu.set_option("fused", 1)
+    try:
+        cam = s.camera(*res) if res else s.camera()
+        g = gpu.render(cam, flags=rt.FLAG_KEEP_ZERO_WEIGHT | (rt.FLAG_PHONG_NORMALS if phong else 0), **kw)
+        parts = [gpu.render(cam, flags=rt.FLAG_KEEP_ZERO_WEIGHT | (rt.FLAG_PHONG_NORMALS if phong else 0), band_rows=8, n_parts=2,
+                            part=p, **kw) for p in range(2)]
+    finally:
+        gpu.set_option("fused", -1)
+    o = oracle_frame(scene, res=res, phong=phong, **kw)
+    assert_frames_match(g, o)
+    assert g["stats"]["closest_rays"] == o["counters"]["closest_rays"]
+    assert g["stats"]["shadow_rays"] == o["counters"]["shadow_rays"]
+    for p in range(2):
+        assert_frames_match(parts[p], o, rows=rt.part_row_indices(cam.resy, 8, 2, p))
+
+
+@pytest.mark.parametrize("scene", ["glass3", "glass"])
+def test_one_launch_kernel_with_light_cameras(gpu, oracle_frame, scene):
+    s = load_scene(gpu, scene)
+    gpu.set_option("fused", 1)
+    try:
+        g = gpu.render(s.camera(), flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    finally:
+        gpu.set_option("fused", -1)
+    o = oracle_frame(scene)
+    assert_frames_match(g, o, tol=1e-6)
+    assert np.array_equal(g["lightcam_mask"], o["lightcam_mask"])
+    assert g["stats"]["closest_rays"] == o["counters"]["closest_rays"]
+    assert g["stats"]["shadow_rays"] == o["counters"]["shadow_rays"]
+
+
 def test_queue_overflow_is_detected_and_rendered_again(gpu, oracle_frame):
     """Ray queues are sized for a multiple of the primary count per generation, not for the 32-fold worst case.
     With the multiple forced to 1 the refraction rays of refract.nff outgrow them: the asynchronous path reports

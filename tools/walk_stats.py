@@ -9,7 +9,7 @@ scene_name, resx, resy, N, _, _ = bench.WORKLOADS[w]
 lib = rt.load()
 fn = C.CDLL(rt.LIB_PATH).rt_debug_counters
 fn.argtypes = [C.POINTER(C.c_ulonglong)]
-s = rt.Scene.load(scene_name); g = rt.Renderer(0); g.upload(s)
+s = rt.Scene.load(scene_name); g = rt.Renderer(0); g.upload(s); g.set_option("fused", 0)
 cam = s.camera(resx, resy)
 buf = (C.c_ulonglong * 48)()
 fn(buf)
