@@ -25,6 +25,7 @@ For N > 1 launch as: python -m torch.distributed.run --nnodes=1 --nproc-per-node
 --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -43,10 +44,20 @@ WORKLOADS = {
     "glass_setup": ("glass", 0, 0, 1, 5, 1),
     "gears": ("gears", 0, 0, 1, 20, 3),
     "balls2": ("balls2", 0, 0, 1, 20, 3),
+    "tetra3": ("tetra-3", 0, 0, 1, 50, 5),
 }
 HBM_PEAK_GBPS = 8000.0
-VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4      # 256 CUs x 4 SIMDs at 2.4 GHz, a 64-wide instruction occupies a SIMD for 4 clocks
+# Vector issue.  Cycles one 64-wide instruction occupies a SIMD, measured on MI355X with every SIMD running four waves
+# of independent instructions (tools/micro/valu_rates.hip, profiles/r02a/valu_rates.jsonl): FP64 add, mul, fma and
+# compare 4.3; FP64 rcp, sqrt (the TRANS counter) 16.2; FP32 fma/mul, integer add, moves 2.4.  (max3/min3 and selects
+# with an explicit mask also take 4.3; they are priced at 2.4 here with everything that is not counted separately,
+# which makes the peak below an upper bound and the fraction a lower one.)
+SIMDS, CLOCK_GHZ = 256 * 4, 2.4
+CYC_FP64, CYC_TRANS64, CYC_OTHER = 4.3, 16.2, 2.4
 BAND_ROWS = 16
+# Bytes this build's own traversal touches per step: one 4-wide node (six 16-byte plane rows and the child codes, 112 of its
+# 128 bytes), the 80 bytes of a leaf triangle record a test reads, a 32-byte sphere record plus key and id.
+BVH_NODE_B, LEAF_TRI_B, LEAF_SPH_B = 128, 80, 40
 
 # Algorithmic bytes per ray (fixed by the reference's traversal, not by what this build fetches):
 #   node tests x 64 B node record + triangle tests x 96 B + sphere tests x 32 B + 192 B of queue
@@ -114,38 +125,63 @@ def cpu_reference_sample(scene_name, resx, resy, N, threads, lightcam=True):
     return out
 
 
-def measured_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the newest committed counter pass of this workload
-    (profiles/<tag>/pmc_<workload>.json, written by tools/pmc_summarize.py from separate rocprofv3 --pmc runs;
-    counters cannot be collected inside a timed run).  None when no such file exists."""
+def _newest_profile(workload, stem):
+    """Newest committed profiles/<tag>/<stem>_<workload>.json, with the build it was measured on."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_%s.json" % workload)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "%s_%s.json" % (stem, workload))))
     if not files:
-        return None
+        return None, None, None
     with open(files[-1]) as f:
         js = json.load(f)
-    n = rd = wr = 0.0
-    hit = req = valu = wait = cyc = insts = 0.0
+    meta = js.get("_meta", {})
+    return js, meta.get("build_id"), os.path.relpath(files[-1], ROOT)
+
+
+def measured_counters(workload, kernel, build_id):
+    """Counter totals of `kernel` from the newest committed counter passes of this workload (separate rocprofv3 --pmc
+    runs, tools/pmc_passes.sh; counters cannot be collected inside a timed run).  Counters of another build of the
+    library are refused: the dict then only says so."""
+    js, their_build, path = _newest_profile(workload, "pmc")
+    if js is None:
+        return None
+    if their_build != build_id:
+        return {"stale": "counters in %s were measured on build %s, this library is build %s: not used" % (path, their_build, build_id)}
+    tot = {}
+    n = 0
+    rd = wr = 0.0
     for name, e in js.items():
-        if not name.startswith(kernel) or "hbm_read_bytes_per_launch" not in e:
+        if name == "_meta" or not name.startswith(kernel) or "hbm_read_bytes_per_launch" not in e:
             continue
         n += e["dispatches"]
         rd += e["hbm_read_bytes_per_launch"] * e["dispatches"]
         wr += e["hbm_write_bytes_per_launch"] * e["dispatches"]
-        hit += e["counters"].get("TCC_HIT_sum", 0.0)
-        req += e["counters"].get("TCC_REQ_sum", 0.0)
-        valu += e["counters"].get("SQ_ACTIVE_INST_VALU", 0.0)
-        wait += e["counters"].get("SQ_WAIT_ANY", 0.0)
-        cyc += e["counters"].get("SQ_WAVE_CYCLES", 0.0)
-        insts += e["counters"].get("SQ_INSTS_VALU", 0.0)
+        for k, v in e["counters"].items():
+            tot[k] = tot.get(k, 0.0) + v
     if n == 0:
         return None
-    return {"bytes_per_launch": (rd + wr) / n, "read": rd / n, "write": wr / n, "launches": int(n),
-            "l2_hit_rate": hit / req if req else None,
-            "valu_issue_share_of_wave_cycles": valu / cyc if cyc else None,
-            "waiting_share_of_wave_cycles": wait / cyc if cyc else None,
-            "valu_instructions_per_launch": insts / n if insts else None,
-            "source": os.path.relpath(files[-1], ROOT)}
+    g = lambda k: tot.get(k, 0.0) / n
+    fp64 = g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64")
+    trans = g("SQ_INSTS_VALU_TRANS_F64")
+    valu = g("SQ_INSTS_VALU")
+    return {"source": path, "build_id": their_build, "launches": int(n),
+            "hbm_read_bytes_per_launch": rd / n, "hbm_write_bytes_per_launch": wr / n,
+            "valu_per_launch": valu, "valu_fp64_per_launch": fp64, "valu_trans64_per_launch": trans,
+            "valu_int32_per_launch": g("SQ_INSTS_VALU_INT32"), "salu_per_launch": g("SQ_INSTS_SALU"),
+            "issue_cycles_per_launch": fp64 * CYC_FP64 + trans * CYC_TRANS64 + max(valu - fp64 - trans, 0.0) * CYC_OTHER,
+            "l2_hit_rate": tot.get("TCC_HIT_sum", 0.0) / tot["TCC_REQ_sum"] if tot.get("TCC_REQ_sum") else None,
+            "lane_utilisation": tot.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * tot["SQ_ACTIVE_INST_VALU"])
+            if tot.get("SQ_ACTIVE_INST_VALU") else None,
+            "waiting_share_of_wave_cycles": tot.get("SQ_WAIT_ANY", 0.0) / tot["SQ_WAVE_CYCLES"] if tot.get("SQ_WAVE_CYCLES") else None}
+
+
+def measured_walk(workload, build_id):
+    """Per-ray traversal work of this build (node steps, leaf tests) from the newest committed run of the counting
+    build (tools/walk_stats.py --json), refused like the counters when it belongs to another build."""
+    js, their_build, path = _newest_profile(workload, "walk")
+    if js is None or their_build != build_id:
+        return None
+    js["source"] = path
+    return js
 
 
 def main():
@@ -226,6 +262,10 @@ def main():
                 gathered[k].record()
         return st
 
+    def last_frame():
+        k = (frame_no[0] - 1) % n_buf
+        return fgs[k].frame if world > 1 else render_bufs[k]
+
     def fence():
         if world > 1:
             dist.barrier()
@@ -266,42 +306,80 @@ def main():
             threads = min(16, os.cpu_count() or 1)
             cpu = cpu_reference_sample(scene_name, resx, resy, N, threads,
                                        lightcam=not (args.flags & rt.FLAG_NO_LIGHTCAM))
-        roofline = None
-        bpr = cpu["bytes_per_ray"] if cpu is not None else RECORDED_BYTES_PER_RAY.get(args.workload)
-        if bpr is not None:
-            # three kernels do the work; the one with the largest total time is the dominant one
+        # ---- roofline of the dominant kernel: the one with the largest total time among the launches of a frame
+        build_id = rt.build_id()
+        if kt["shadow_launches"] == 0 and kt["closest_launches"] == kt["primary_launches"]:
+            classes = {"k_fused": ("fused", kt["primary_ms"], kt["primary_launches"], kt["closest_rays"] + kt["shadow_rays"])}
+        else:
             classes = {
-                "k_closest<true, true>": ("closest", kt["primary_ms"], kt["primary_launches"], kt["primary_rays"]),
-                "k_closest<false, true>": ("closest", kt["closest_ms"] - kt["primary_ms"],
+                "k_closest<true, true>": ("primary", kt["primary_ms"], kt["primary_launches"], kt["primary_rays"]),
+                "k_closest<false, true>": ("queued", kt["closest_ms"] - kt["primary_ms"],
                                            kt["closest_launches"] - kt["primary_launches"],
                                            kt["closest_rays"] - kt["primary_rays"]),
                 "k_shadow<true>": ("shadow", kt["shadow_ms"], kt["shadow_launches"], kt["shadow_rays"]),
             }
-            kname = max(classes, key=lambda k: classes[k][1])
-            dom, ms_total, launches, rays_k = classes[kname]
-            launches = max(launches, 1)
-            bytes_total = rays_k * bpr[dom]
-            achieved = bytes_total / (ms_total * 1e-3) / 1e9 if ms_total > 0 else 0.0
-            # (for N > 1 the launches, their rays and their times are rank 0's own; the counter passes are one-GPU runs)
-            tr = measured_traffic(args.workload, kname) if world == 1 else None
-            roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBPS, "traffic": tr["bytes_per_launch"] if tr else None,
-                        "traffic_detail": tr,
-                        "algorithmic_bytes_per_launch": bytes_total / launches,
-                        "note": "achieved counts the bytes of the reference's own traversal (its node and primitive "
-                                "tests per ray); this build answers the same queries with far fewer tests and keeps "
-                                "the scene in cache, so frac can exceed 1 and HBM is not what limits the kernel; "
-                                "kernel names as rocprofv3 prints them for scenes that use the hierarchies",
-                        "avg_launch_ms": ms_total / launches, "launches": launches,
-                        "algorithmic_bytes_per_ray": bpr[dom], "rays_per_launch": rays_k / launches,
-                        "kernel_ms_per_frame": {k: v[1] / prof_steps for k, v in classes.items()},
-                        "frame_gpu_ms": kt["gpu_ms"] / prof_steps}
-            if tr and tr.get("valu_instructions_per_launch"):
-                # the limit that is actually near: wave-level vector instructions (counter pass) over the live launch
-                # time, against one instruction per SIMD every four clocks
-                rate = tr["valu_instructions_per_launch"] / (ms_total / launches * 1e-3) / 1e9
-                roofline["vector_issue"] = {"achieved": rate, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instructions/s",
-                                            "frac": rate / VALU_PEAK_GINSTR}
+        kname = max(classes, key=lambda k: classes[k][1])
+        dom, ms_total, launches, rays_k = classes[kname]
+        launches = max(launches, 1)
+        avg_ms = ms_total / launches
+        # (for N > 1 the launches, their rays and their times are rank 0's own; the counter passes are one-GPU runs)
+        ctr = measured_counters(args.workload, kname, build_id) if world == 1 else None
+        stale = ctr.get("stale") if ctr else None
+        if stale:
+            ctr = None
+        walk = measured_walk(args.workload, build_id) if world == 1 else None
+        roofline = {"bound": "valu_issue", "kernel": kname, "avg_launch_ms": avg_ms, "launches": launches,
+                    "rays_per_launch": rays_k / launches, "build_id": build_id,
+                    "kernel_ms_per_frame": {k: v[1] / prof_steps for k, v in classes.items()},
+                    "frame_gpu_ms": kt["gpu_ms"] / prof_steps,
+                    "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None}
+        if stale:
+            roofline["counters"] = stale
+        if ctr:
+            # Vector issue: wave-level vector instructions per launch (counter pass) over the live launch time, against what
+            # the SIMDs can issue of THIS kernel's instruction mix (cycles per instruction by kind, see CYC_* above).
+            rate = ctr["valu_per_launch"] / (avg_ms * 1e-3) / 1e9
+            peak = SIMDS * CLOCK_GHZ / (ctr["issue_cycles_per_launch"] / ctr["valu_per_launch"])
+            hbm_bytes = ctr["hbm_read_bytes_per_launch"] + ctr["hbm_write_bytes_per_launch"]
+            hbm_rate = hbm_bytes / (avg_ms * 1e-3) / 1e9
+            roofline.update({
+                "achieved": rate, "peak": peak, "frac": rate / peak, "traffic": hbm_bytes,
+                "issue_cycles_per_instruction": ctr["issue_cycles_per_launch"] / ctr["valu_per_launch"],
+                "valu_wave_instructions_per_64_rays": ctr["valu_per_launch"] / max(rays_k / launches / 64.0, 1),
+                "hbm": {"achieved": hbm_rate, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_rate / HBM_PEAK_GBPS,
+                        "read_bytes_per_launch": ctr["hbm_read_bytes_per_launch"],
+                        "write_bytes_per_launch": ctr["hbm_write_bytes_per_launch"], "l2_hit_rate": ctr["l2_hit_rate"]},
+                "counters": {k: ctr[k] for k in ("source", "build_id", "launches", "valu_per_launch", "valu_fp64_per_launch",
+                                                 "valu_trans64_per_launch", "valu_int32_per_launch", "salu_per_launch",
+                                                 "lane_utilisation", "waiting_share_of_wave_cycles")}})
+        if walk and dom in walk:
+            # what this build's own traversal needs per ray: node steps and leaf tests counted by the -DRT_COUNT build,
+            # plus the queue records the kernel reads and writes
+            w = walk[dom]
+            queue_b = {"primary": 64 + 80, "queued": 80 + 64 + 80, "shadow": 64 / max(walk.get("lights", 1), 1) + 24,
+                       "fused": 24}[dom]
+            alg = w["nodes_per_ray"] * BVH_NODE_B + w["tri_tests_per_ray"] * LEAF_TRI_B + w["sph_tests_per_ray"] * LEAF_SPH_B + queue_b
+            roofline["algorithmic"] = {"bytes_per_ray": alg, "bytes_per_launch": alg * rays_k / launches,
+                                       "node_steps_per_ray": w["nodes_per_ray"], "leaf_tests_per_ray": w["tri_tests_per_ray"] + w["sph_tests_per_ray"],
+                                       "queue_bytes_per_ray": queue_b, "source": walk["source"],
+                                       "note": "most of it is served from LDS and L2 (the scene is smaller than either); only the "
+                                               "queue records have to come from HBM"}
+        bpr = cpu["bytes_per_ray"] if cpu is not None else RECORDED_BYTES_PER_RAY.get(args.workload)
+        if bpr is not None and dom in ("primary", "queued", "shadow"):
+            ref_dom = "shadow" if dom == "shadow" else "closest"
+            roofline["reference_algorithm_bytes"] = {
+                "bytes_per_ray": bpr[ref_dom], "bytes_per_launch": bpr[ref_dom] * rays_k / launches,
+                "note": "node and primitive tests of the REFERENCE's octree walk per ray x record sizes + 192 B of queue "
+                        "traffic; this build answers the same queries with a fraction of those tests, so this is not a "
+                        "measure of what the kernel moves and no fraction is formed from it"}
+        # the timed frame itself: checksum of its 8-bit image, and whether it is the frame the GPU tests pin
+        frame_sha = hashlib.sha256(last_frame().cpu().numpy().tobytes()).hexdigest()
+        pinned = None
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+                pinned = json.load(f).get("frame_sha256", {}).get(args.workload)
+        except OSError:
+            pass
         line = {
             "metric": "Mrays/sec (primary+secondary)",
             "value": rays / elapsed / 1e6,
@@ -320,8 +398,10 @@ def main():
                        "partition": "%d-row bands round-robin over %d GPU(s), %s gather of RGB8"
                                     % (band or resy, world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal)")},
         }
-        if roofline is not None:
-            line["roofline"] = roofline
+        line["frame_sha256"] = frame_sha
+        line["frame_matches_pinned"] = (frame_sha == pinned) if pinned else None
+        line["output"] = "RGB8 frame in device memory (the double frame of the boundary is not written in the timed steps)"
+        line["roofline"] = roofline
         if cpu is not None:
             line["cpu_baseline"] = {"value": cpu["all"]["mrays_s"], "unit": "Mrays/s", "cores": cpu["all"]["threads"],
                                     "kind": "port", "sample": cpu["sample"],

@@ -165,6 +165,8 @@ typedef struct rth_scene rth_scene;
 
 /* ---- device path ---- */
 const char *rt_last_error(void);
+/* Identity of the sources this library was built from (16 hex digits); measurements kept beside the code name it. */
+const char *rt_build_id(void);
 int rt_device_count(int *count);
 int rt_create(int device_id, rt_ctx **out);
 int rt_destroy(rt_ctx *ctx);

@@ -109,6 +109,7 @@ class Stats(C.Structure):
 # Every symbol the header declares, with its signature; load() checks that all are exported.
 _SIGNATURES = {
     "rt_last_error": (C.c_char_p, []),
+    "rt_build_id": (C.c_char_p, []),
     "rt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "rt_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "rt_destroy": (C.c_int, [C.c_void_p]),
@@ -273,6 +274,10 @@ class Scene:
         if d.n_lights == 0:
             return np.zeros((0, 8))
         return np.ctypeslib.as_array(C.cast(d.lights, C.POINTER(C.c_double)), shape=(d.n_lights, 8))
+
+
+def build_id():
+    return load().rt_build_id().decode()
 
 
 def noalloc_scratch_bytes():

@@ -26,6 +26,20 @@ DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-
 HOST_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-value"]
 
 
+def source_id():
+    """Identity of the sources the library is built from: sha256 over csrc/*.{hip,hpp,cpp} and the public header,
+    16 hex digits.  Compiled into the library (rt_build_id) so that measurements can name the build they belong to."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".cpp"))]
+    files.append(os.path.join(ROOT, "include", "raytracer_amd.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if cand and os.path.exists(cand):
@@ -64,8 +78,13 @@ def build_library(force=False):
     if force or _newer(lc_obj, [lc_src, lc_hdr, os.path.abspath(__file__)]):
         _run(["g++"] + HOST_FLAGS + ["-c", lc_src, "-o", lc_obj])
     dev_hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")]
-    if force or _newer(dev_obj, [dev_src, header, os.path.abspath(__file__)] + dev_hdrs):
-        _run([hipcc] + DEVICE_FLAGS + ["-c", dev_src, "-o", dev_obj])
+    sid = source_id()
+    id_file = os.path.join(CSRC, ".build_id")
+    built_id = open(id_file).read().strip() if os.path.exists(id_file) else ""
+    if force or built_id != sid or _newer(dev_obj, [dev_src, header, os.path.abspath(__file__)] + dev_hdrs):
+        _run([hipcc] + DEVICE_FLAGS + ['-DRT_BUILD_ID="%s"' % sid, "-c", dev_src, "-o", dev_obj])
+        with open(id_file, "w") as f:
+            f.write(sid + "\n")
     if force or _newer(host_obj, [host_src, header, os.path.join(CSRC, "host_scene.hpp"), os.path.abspath(__file__)]):
         _run(["g++"] + HOST_FLAGS + ["-c", host_src, "-o", host_obj])
     if force or _newer(accel_obj, [accel_src, accel_hdr, header, os.path.abspath(__file__)]):
@@ -99,4 +118,7 @@ def build_all(force=False):
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if "--source-id" in sys.argv:
+        print(source_id())
+    else:
+        build_all(force="--force" in sys.argv)

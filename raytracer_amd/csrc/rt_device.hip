@@ -309,6 +309,11 @@ extern "C" int rt_debug_stamps(unsigned long long *out, int n_words)
 }
 #endif
 
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"
+#endif
+extern "C" const char *rt_build_id(void) { return RT_BUILD_ID; }
+
 extern "C" int rt_set_batch(rt_ctx *ctx, int64_t primaries)
 {
     if (!ctx || primaries < 0) return fail(RT_ERR_INVALID, "rt_set_batch: bad argument");

@@ -1,12 +1,27 @@
 #!/bin/bash
-# Collects the per-round evidence: bench JSON lines, rocprofv3 kernel stats, PMC summary.
-# usage: tools/collect_profiles.sh <round-tag>   (run on the GPU box; copies land in gpurun_out/<tag>/)
+# Collects the per-round evidence: bench JSON lines, rocprofv3 kernel stats, counter passes, traversal statistics.
+# usage: tools/collect_profiles.sh <round-tag>   (run on the GPU box; copies land in gpurun_out/<tag>/, from where the
+# files to be judged are copied into profiles/<tag>/).  Needs build_variants/lib_count.so (tools/build_variant.sh count
+# -DRT_COUNT) and build_variants/valu_rates, both built from the same sources as the product library.
 tag=$1
 out=gpurun_out/$tag
 mkdir -p $out
 R=$PWD
 export TMPDIR=/tmp
-for w in teapot3_8k16 teapot3 balls refract glass glass_setup gears balls2; do
+# traversal statistics of this build and the issue rates they are priced with: read by bench.py, so first
+for w in teapot3_8k16 teapot3 balls refract; do
+  RAYTRACER_AMD_LIB=build_variants/lib_count.so timeout -k 10 200 python tools/walk_stats.py $w --json=$out/walk_$w.json > $out/walk_$w.txt 2>&1 || { echo "walk_stats $w failed"; tail -3 $out/walk_$w.txt; exit 1; }
+done
+timeout -k 10 120 build_variants/valu_rates > $out/valu_rates.jsonl || exit 1
+# counters of the default workload (separate passes), then the same for a small frame
+tools/pmc_passes.sh $tag --workload teapot3_8k16 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_log.txt 2>&1 || { tail -5 $out/pmc_log.txt; exit 1; }
+cp gpurun_out/pmc_${tag}_summary.txt $out/pmc_summary_teapot3_8k16.txt
+cp gpurun_out/pmc_${tag}.json $out/pmc_teapot3_8k16.json
+tools/pmc_quick.sh ${tag}q --workload teapot3_8k16 --steps 1 --warmup 0 --no-cpu-baseline > $out/units_teapot3_8k16.txt 2>&1 || { tail -5 $out/units_teapot3_8k16.txt; exit 1; }
+# bench lines (they read the counters above through profiles/: copy first)
+mkdir -p profiles/$tag
+cp $out/pmc_teapot3_8k16.json $out/walk_*.json profiles/$tag/
+for w in teapot3_8k16 teapot3 balls refract glass glass_setup gears balls2 tetra3; do
   timeout -k 10 400 python bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err || { echo "bench $w failed"; tail -3 $out/bench_$w.err; exit 1; }
 done
 cd /tmp
@@ -15,9 +30,5 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$ou
 cd $R
 cp $out/trace_8k16/k_kernel_stats.csv $out/kernel_stats_teapot3_8k16.csv
 cp $out/trace_teapot3/k_kernel_stats.csv $out/kernel_stats_teapot3.csv
-tools/pmc_passes.sh $tag --workload teapot3_8k16 --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_log.txt 2>&1 || { tail -5 $out/pmc_log.txt; exit 1; }
-cp gpurun_out/pmc_${tag}_summary.txt $out/pmc_summary_teapot3_8k16.txt
-cp gpurun_out/pmc_${tag}.json $out/pmc_teapot3_8k16.json
-tools/pmc_quick.sh ${tag}q --workload teapot3_8k16 --steps 1 --warmup 0 --no-cpu-baseline > $out/units_teapot3_8k16.txt 2>&1 || { tail -5 $out/units_teapot3_8k16.txt; exit 1; }
 rm -rf $out/trace_8k16 $out/trace_teapot3
 ls $out

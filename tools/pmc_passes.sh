@@ -17,4 +17,5 @@ run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_T
 run fetch FETCH_SIZE &&
 run write WRITE_SIZE GRBM_GUI_ACTIVE
 cd $R
-python3 tools/pmc_summarize.py $tag
+wl=teapot3_8k16; for ((i=0;i<${#BARGS[@]};i++)); do [ "${BARGS[$i]}" = "--workload" ] && wl=${BARGS[$((i+1))]}; done
+python3 tools/pmc_summarize.py $tag $wl

@@ -18,6 +18,8 @@ python3 - $tag <<'PY'
 import json, sys
 j = json.load(open("gpurun_out/pmc_%s.json" % sys.argv[1]))
 for k, e in j.items():
+    if k == "_meta":
+        continue
     c = e["counters"]
     if "closest" not in k and "shadow" not in k and "lightcam" not in k:
         continue

@@ -3,8 +3,10 @@
 Writes gpurun_out/pmc_<tag>_summary.txt (readable) and gpurun_out/pmc_<tag>.json (per kernel: dispatches,
 counter totals, and the derived per-launch HBM bytes: FETCH_SIZE and WRITE_SIZE are in KiB, and on gfx950
 FETCH_SIZE tallies the 128-byte requests of wide loads at 64 bytes, so read bytes are doubled)."""
-import csv, glob, json, os, sys, collections
+import csv, glob, json, os, subprocess, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else None
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(set)
 for d in sorted(glob.glob("gpurun_out/pmc_%s_*" % tag)):
@@ -36,6 +38,15 @@ for k in sorted(agg):
     js[k.replace("void ", "")] = e
     for c in sorted(agg[k]):
         out.append("    %-34s %.6g" % (c, agg[k][c]))
+# the build the counters belong to: bench.py refuses counters of another build
+import raytracer_amd as rt
+meta = {"build_id": rt.build_id(), "workload": workload}
+try:
+    meta["git"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except OSError:
+    meta["git"] = None
+js["_meta"] = meta
+out.insert(0, "build %s  workload %s" % (meta["build_id"], workload))
 txt = "\n".join(out)
 print(txt)
 open("gpurun_out/pmc_%s_summary.txt" % tag, "w").write(txt + "\n")

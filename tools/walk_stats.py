@@ -4,7 +4,9 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
 import bench
-w = sys.argv[1] if len(sys.argv) > 1 else "teapot3"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+w = args[0] if args else "teapot3"
+json_out = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--json=")]
 scene_name, resx, resy, N, _, _ = bench.WORKLOADS[w]
 lib = rt.load()
 fn = C.CDLL(rt.LIB_PATH).rt_debug_counters
@@ -17,9 +19,15 @@ fr = g.render(cam, num_samples=N, want=("rgb_u8",))
 fn(buf)
 names = ["rays", "lane_nodes", "wave_nodes", "lane_prims", "wave_prims", "lane_leaves", "wave_rounds"]
 print(w, fr["stats"]["closest_rays"], fr["stats"]["shadow_rays"])
+record = {"_meta": {"build_id": rt.build_id(), "workload": w}, "lights": int(s.desc.n_lights)}
+tri_share = 1.0 if s.desc.n_sph_slots == 0 else (0.0 if s.desc.n_tri_slots == 0 else 0.5)
 for gi, gname in enumerate(("primary", "queued", "shadow")):
     v = dict(zip(names, list(buf[gi * 8:gi * 8 + 7])))
     r = max(v["rays"], 1)
+    record[gname] = {"rays": v["rays"], "nodes_per_ray": v["lane_nodes"] / r, "leaves_per_ray": v["lane_leaves"] / r,
+                     "tri_tests_per_ray": v["lane_prims"] / r * tri_share, "sph_tests_per_ray": v["lane_prims"] / r * (1 - tri_share),
+                     "wave_node_steps_per_64_rays": v["wave_nodes"] * 64 / r, "wave_leaf_tests_per_64_rays": v["wave_prims"] * 64 / r,
+                     "wave_rounds_per_64_rays": v["wave_rounds"] * 64 / r}
     print("%-8s rays %11d | per ray: nodes %.2f leaves %.2f prims %.2f | per 64 rays the wave ran: node steps %.1f prim tests %.1f rounds %.1f"
           % (gname, v["rays"], v["lane_nodes"] / r, v["lane_leaves"] / r, v["lane_prims"] / r,
              v["wave_nodes"] * 64 / r, v["wave_prims"] * 64 / r, v["wave_rounds"] * 64 / r))
@@ -33,3 +41,7 @@ if t[0]:
     w = t[0]
     print("lightcam waves %d | per wave: %.0f ticks (100 MHz clock) in the query, %.0f of them in %.1f cooperative phases, slowest lane %.1f trips | "
           "longest wave %d ticks, %d trips" % (w, t[1] / w, t[2] / w, t[4] / w, t[3] / w, t[5], t[6]))
+if json_out:
+    import json
+    with open(json_out[0], "w") as f:
+        json.dump(record, f, indent=1, sort_keys=True)
