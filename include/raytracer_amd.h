@@ -158,6 +158,8 @@ typedef struct rt_stats {
     int32_t queue_overflow;
     double primary_ms;         /* only with RT_FLAG_TIMING: the share of closest_ms spent in generation 0 */
     uint64_t primary_launches; /* (ray generation fused with the closest-hit query; one launch per batch) */
+    double pair_ms;            /* only with RT_FLAG_TIMING: launches that run the shadow pass of one generation together with */
+    uint64_t pair_launches;    /* the closest-hit pass of the next (counted here, not in closest_ms / shadow_ms) */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

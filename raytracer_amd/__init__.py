@@ -96,7 +96,8 @@ class Stats(C.Structure):
                 ("gpu_ms", C.c_double), ("closest_ms", C.c_double), ("shadow_ms", C.c_double),
                 ("other_ms", C.c_double), ("closest_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
                 ("batches", C.c_int32), ("queue_overflow", C.c_int32),
-                ("primary_ms", C.c_double), ("primary_launches", C.c_uint64)]
+                ("primary_ms", C.c_double), ("primary_launches", C.c_uint64),
+                ("pair_ms", C.c_double), ("pair_launches", C.c_uint64)]
 
     def as_dict(self):
         d = {}

@@ -105,6 +105,10 @@ inline FastDiv make_fastdiv(uint32_t d)
     return f;
 }
 
+// The parameters of a frame, passed to the kernels by value.  (Passed as a pointer to a copy in device memory instead,
+// so that fields are fetched where they are used rather than all at kernel entry: the scalar-register spills of the
+// traversal kernels fall from 50-100 to under 10, but without `restrict` every field is fetched again inside the walks
+// -- the 8K frame 70 -> 84 ms -- and with it the spills and the time are what they are by value, plus a copy per frame.)
 struct FrameParams {
     DevScene S;
     rt_camera cam;

@@ -107,6 +107,142 @@ DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, i
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
+// One 64-ray chunk of a closest-hit pass: the rays (generated, or read from the queue), the closest-hit query, the hit
+// record and the pushes of the hit and of the secondary rays.
+template <bool PRIMARY, bool BVH>
+DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &smap, long long chunk, int lane, int *stack, bool cull,
+                       WalkCount &wc)
+{
+#define STAMP_SEL (Q.generation)
+    bool active;
+    d3 o, d;
+    double A = 1.0, coef = 1.0;
+    uint32_t pixel = 0, meta = 5u | 0x100u;
+    bool first_sample = false;
+    if (PRIMARY) {
+        primary_ray(P, Q, chunk, lane, &active, &o, &d, &pixel, &first_sample);
+    } else {
+        int shard;
+        const int local = shard_locate(smap, (uint32_t)chunk, &shard);
+        active = local >= 0;
+        const RayRec *rr = &Q.rays_in[active ? (size_t)shard * Q.in_shard_cap + (uint32_t)local : 0];
+        const rec_v2d r0 = rec_load(rr, 0), r1 = rec_load(rr, 1), r2 = rec_load(rr, 2), r3 = rec_load(rr, 3), r4 = rec_load(rr, 4);
+        o = mk3(r0.x, r0.y, r1.x);
+        d = mk3(r1.y, r2.x, r2.y);
+        A = r3.x;
+        coef = r3.y;
+        pixel = (uint32_t)__double2loint(r4.x);
+        meta = (uint32_t)__double2hiint(r4.x);
+    }
+
+    double best_t = 0;
+    int best = -1, best_prim = -1;
+    STAMP(3);
+    if (active) {
+        if (BVH) {
+            const double d2 = dot3(d, d);
+            Best bst;
+            bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1; bst.prim = -1;
+            if (root_gate(P.S, o, d, d2, 10000000000.0)) {
+                const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
+                WC_ADD(wc, rays);
+                bvh_closest<true>(P.S, o, d, d2, rb, bst, stack, wc);
+                bvh_closest<false>(P.S, o, d, d2, rb, bst, stack, wc);
+            }
+            best_t = bst.t;
+            best = bst.slot;
+            best_prim = bst.prim;
+        } else {
+            trace_closest(P.S, o, d, cull, .01, best_t, best);
+        }
+    }
+    const rt_tri_rec *tri_arr = BVH ? P.S.btri : P.S.tri;
+    const rt_sph_rec *sph_arr = BVH ? P.S.bsph : P.S.sph;
+    const uint32_t *sph_prim_arr = BVH ? P.S.bsph_prim : P.S.sph_prim;
+    STAMP(4);
+
+    const bool first = (meta & 0x100u) != 0;
+    const int L = (int)(meta & 0xffu);
+    const double wloc = first ? A : A * coef;
+    bool hit = active && best >= 0;
+
+    // hit record (Solid.h:110-125)
+    d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0);
+    int prim = -1, mat = 0;
+    bool flat = false;
+    rt_material m;
+    m.Ks = 0; m.T = 0; m.ior = 1;
+    if (hit) {
+        hit_geometry(P.S, tri_arr, sph_arr, sph_prim_arr, P.flags, o, d, .01, best_t, best, best_prim, &prim, &n, &Pt, &flat);
+        mat = P.S.prim_material[prim];
+        m = load_material(P.S, mat, true);
+    }
+    if (PRIMARY && active && first_sample && P.hit_id) P.hit_id[pixel] = prim;
+    // misses add the background (placed after the hit's table fetches have been issued, so that their
+    // latency runs beside the shuffles and atomics of this sum)
+    STAMP(5);
+    accum_add_runs(P.accum, active, active && !hit, pixel, wloc, ld3(P.S.bg));
+    STAMP(6);
+
+    // Queue pushes.  The three reservations (hit record, refraction ray, reflection ray) are made
+    // with two atomics -- both kinds of ray go to the same queue -- issued back to back by one lane,
+    // so a wave waits for one round trip to the counters instead of three in a row.
+    const bool want_hit = hit && P.S.n_lights > 0;
+    const bool spawn = hit && L > 0 && !(coef < .01);       // Camera.h:244-307
+    const double coef2 = coef * m.Ks;
+    const bool want_refr = spawn && m.T > 0;
+    const bool want_refl = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
+    const unsigned long long mask_h = __ballot(want_hit), mask_a = __ballot(want_refr), mask_b = __ballot(want_refl);
+    const uint32_t n_h = (uint32_t)__popcll(mask_h), n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b);
+    const uint32_t shard = blockIdx.x & (N_SHARDS - 1);
+    uint32_t base_h = 0, base_r = 0;
+    if (lane == 0) {
+        if (n_h) base_h = atomicAdd(&Q.counts[CNT_HITS(Q.generation) + shard], n_h);
+        if (n_a + n_b) base_r = atomicAdd(&Q.counts[CNT_RAYS(Q.generation + 1) + shard], n_a + n_b);
+    }
+    base_h = (uint32_t)__shfl((int)base_h, 0);
+    base_r = (uint32_t)__shfl((int)base_r, 0);
+    STAMP(7);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t slot_h = base_h + (uint32_t)__popcll(mask_h & below);
+    const uint32_t slot_a = base_r + (uint32_t)__popcll(mask_a & below);
+    const uint32_t slot_b = base_r + n_a + (uint32_t)__popcll(mask_b & below);
+    if ((want_hit && slot_h >= Q.hit_shard_cap) || (want_refr && slot_a >= Q.out_shard_cap) ||
+        (want_refl && slot_b >= Q.out_shard_cap))
+        Q.counts[CNT_OVERFLOW] = 1u;
+
+    if (want_hit && slot_h < Q.hit_shard_cap) {
+        const d3 vv = unit3(sub3(o, Pt));
+        HitRec *dst = (HitRec *)((char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + slot_h) * Q.hit_stride);
+        // HitRec: P, v, weight, pixel, prim -- and for a hit whose normal is not its primitive's tabulated one
+        // (a sphere, interpolated vertex normals) the material and the normal normalised twice and thrice
+        const rec_v2d q[4] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, vv.x), rec_pack(vv.y, vv.z),
+                              rec_pack(wloc, __hiloint2double(prim, (int)(pixel | (flat ? HIT_FLAT : 0u))))};
+        rec_store(dst, q);
+        if (!flat) {
+            const d3 n2 = unit3(n), n3 = unit3(n2);
+            const rec_v2d r[4] = {rec_pack_words(0u, 0u, (uint32_t)mat, 0u), rec_pack(n2.x, n2.y), rec_pack(n2.z, n3.x), rec_pack(n3.y, n3.z)};
+            rec_store(&dst->light, r);
+        }
+    }
+    if (want_refr && slot_a < Q.out_shard_cap) {
+        const d3 rd = refract_dir(d, n, m.ior, false);
+        // RayRec: o, d, A, coef, pixel, meta, pad
+        const rec_v2d q[5] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, rd.x), rec_pack(rd.y, rd.z), rec_pack(A * m.T, m.T * coef),
+                              rec_pack_words(pixel, (uint32_t)(L - 1) | 0x100u, 0u, 0u)};
+        rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_a], q);
+    }
+    if (want_refl && slot_b < Q.out_shard_cap) {
+        const d3 refl = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));      // hr.reflectionDir (Solid.h:121-122), only where a ray follows it
+        const rec_v2d q[5] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, refl.x), rec_pack(refl.y, refl.z), rec_pack(A, coef2),
+                              rec_pack_words(pixel, (uint32_t)(L - 1), 0u, 0u)};
+        rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_b], q);
+    }
+    STAMP(8);
+
+#undef STAMP_SEL
+}
+
 template <bool PRIMARY, bool BVH>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams P, QueueSet Q)
 {
@@ -130,131 +266,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
     WalkCount wc{};
 
     for (long long chunk = next_chunk(P.S); chunk < n_chunks; chunk = next_chunk(P.S)) {
-        bool active;
-        d3 o, d;
-        double A = 1.0, coef = 1.0;
-        uint32_t pixel = 0, meta = 5u | 0x100u;
-        bool first_sample = false;
-        if (PRIMARY) {
-            primary_ray(P, Q, chunk, lane, &active, &o, &d, &pixel, &first_sample);
-        } else {
-            int shard;
-            const int local = shard_locate(smap, (uint32_t)chunk, &shard);
-            active = local >= 0;
-            const RayRec *rr = &Q.rays_in[active ? (size_t)shard * Q.in_shard_cap + (uint32_t)local : 0];
-            const rec_v2d r0 = rec_load(rr, 0), r1 = rec_load(rr, 1), r2 = rec_load(rr, 2), r3 = rec_load(rr, 3), r4 = rec_load(rr, 4);
-            o = mk3(r0.x, r0.y, r1.x);
-            d = mk3(r1.y, r2.x, r2.y);
-            A = r3.x;
-            coef = r3.y;
-            pixel = (uint32_t)__double2loint(r4.x);
-            meta = (uint32_t)__double2hiint(r4.x);
-        }
-
-        double best_t = 0;
-        int best = -1, best_prim = -1;
-        STAMP(3);
-        if (active) {
-            if (BVH) {
-                const double d2 = dot3(d, d);
-                Best bst;
-                bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1; bst.prim = -1;
-                if (root_gate(P.S, o, d, d2, 10000000000.0)) {
-                    const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
-                    WC_ADD(wc, rays);
-                    bvh_closest<true>(P.S, o, d, d2, rb, bst, stack, wc);
-                    bvh_closest<false>(P.S, o, d, d2, rb, bst, stack, wc);
-                }
-                best_t = bst.t;
-                best = bst.slot;
-                best_prim = bst.prim;
-            } else {
-                trace_closest(P.S, o, d, cull, .01, best_t, best);
-            }
-        }
-        const rt_tri_rec *tri_arr = BVH ? P.S.btri : P.S.tri;
-        const rt_sph_rec *sph_arr = BVH ? P.S.bsph : P.S.sph;
-        const uint32_t *sph_prim_arr = BVH ? P.S.bsph_prim : P.S.sph_prim;
-        STAMP(4);
-
-        const bool first = (meta & 0x100u) != 0;
-        const int L = (int)(meta & 0xffu);
-        const double wloc = first ? A : A * coef;
-        bool hit = active && best >= 0;
-
-        // hit record (Solid.h:110-125)
-        d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0);
-        int prim = -1, mat = 0;
-        bool flat = false;
-        rt_material m;
-        m.Ks = 0; m.T = 0; m.ior = 1;
-        if (hit) {
-            hit_geometry(P.S, tri_arr, sph_arr, sph_prim_arr, P.flags, o, d, .01, best_t, best, best_prim, &prim, &n, &Pt, &flat);
-            mat = P.S.prim_material[prim];
-            m = load_material(P.S, mat, true);
-        }
-        if (PRIMARY && active && first_sample && P.hit_id) P.hit_id[pixel] = prim;
-        // misses add the background (placed after the hit's table fetches have been issued, so that their
-        // latency runs beside the shuffles and atomics of this sum)
-        STAMP(5);
-        accum_add_runs(P.accum, active, active && !hit, pixel, wloc, ld3(P.S.bg));
-        STAMP(6);
-
-        // Queue pushes.  The three reservations (hit record, refraction ray, reflection ray) are made
-        // with two atomics -- both kinds of ray go to the same queue -- issued back to back by one lane,
-        // so a wave waits for one round trip to the counters instead of three in a row.
-        const bool want_hit = hit && P.S.n_lights > 0;
-        const bool spawn = hit && L > 0 && !(coef < .01);       // Camera.h:244-307
-        const double coef2 = coef * m.Ks;
-        const bool want_refr = spawn && m.T > 0;
-        const bool want_refl = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
-        const unsigned long long mask_h = __ballot(want_hit), mask_a = __ballot(want_refr), mask_b = __ballot(want_refl);
-        const uint32_t n_h = (uint32_t)__popcll(mask_h), n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b);
-        const uint32_t shard = blockIdx.x & (N_SHARDS - 1);
-        uint32_t base_h = 0, base_r = 0;
-        if (lane == 0) {
-            if (n_h) base_h = atomicAdd(&Q.counts[CNT_HITS(Q.generation) + shard], n_h);
-            if (n_a + n_b) base_r = atomicAdd(&Q.counts[CNT_RAYS(Q.generation + 1) + shard], n_a + n_b);
-        }
-        base_h = (uint32_t)__shfl((int)base_h, 0);
-        base_r = (uint32_t)__shfl((int)base_r, 0);
-        STAMP(7);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const uint32_t slot_h = base_h + (uint32_t)__popcll(mask_h & below);
-        const uint32_t slot_a = base_r + (uint32_t)__popcll(mask_a & below);
-        const uint32_t slot_b = base_r + n_a + (uint32_t)__popcll(mask_b & below);
-        if ((want_hit && slot_h >= Q.hit_shard_cap) || (want_refr && slot_a >= Q.out_shard_cap) ||
-            (want_refl && slot_b >= Q.out_shard_cap))
-            Q.counts[CNT_OVERFLOW] = 1u;
-
-        if (want_hit && slot_h < Q.hit_shard_cap) {
-            const d3 vv = unit3(sub3(o, Pt));
-            HitRec *dst = (HitRec *)((char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + slot_h) * Q.hit_stride);
-            // HitRec: P, v, weight, pixel, prim -- and for a hit whose normal is not its primitive's tabulated one
-            // (a sphere, interpolated vertex normals) the material and the normal normalised twice and thrice
-            const rec_v2d q[4] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, vv.x), rec_pack(vv.y, vv.z),
-                                  rec_pack(wloc, __hiloint2double(prim, (int)(pixel | (flat ? HIT_FLAT : 0u))))};
-            rec_store(dst, q);
-            if (!flat) {
-                const d3 n2 = unit3(n), n3 = unit3(n2);
-                const rec_v2d r[4] = {rec_pack_words(0u, 0u, (uint32_t)mat, 0u), rec_pack(n2.x, n2.y), rec_pack(n2.z, n3.x), rec_pack(n3.y, n3.z)};
-                rec_store(&dst->light, r);
-            }
-        }
-        if (want_refr && slot_a < Q.out_shard_cap) {
-            const d3 rd = refract_dir(d, n, m.ior, false);
-            // RayRec: o, d, A, coef, pixel, meta, pad
-            const rec_v2d q[5] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, rd.x), rec_pack(rd.y, rd.z), rec_pack(A * m.T, m.T * coef),
-                                  rec_pack_words(pixel, (uint32_t)(L - 1) | 0x100u, 0u, 0u)};
-            rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_a], q);
-        }
-        if (want_refl && slot_b < Q.out_shard_cap) {
-            const d3 refl = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));      // hr.reflectionDir (Solid.h:121-122), only where a ray follows it
-            const rec_v2d q[5] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, refl.x), rec_pack(refl.y, refl.z), rec_pack(A, coef2),
-                                  rec_pack_words(pixel, (uint32_t)(L - 1), 0u, 0u)};
-            rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_b], q);
-        }
-        STAMP(8);
+        closest_chunk<PRIMARY, BVH>(P, Q, smap, chunk, lane, stack, cull, wc);
     }
     STAMP(9);
 #ifdef RT_COUNT
@@ -274,6 +286,113 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
 #define SHADOW_BVH 1
 #define SHADOW_HYBRID 2
 #define MAX_HYBRID_SPHERES 64
+// One 64-item chunk of a shadow/shading pass; the items are (hit, light) pairs, the lights of one hit in consecutive items.
+template <int MODE>
+DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &smap, uint32_t nl, long long chunk, int *stack, bool cull,
+                      WalkCount &wc)
+{
+#define STAMP_SEL (8 + Q.generation)
+    int shard;
+    const int item = shard_locate(smap, (uint32_t)chunk, &shard);
+    const bool active = item >= 0;
+    const uint32_t h = active ? (uint32_t)item / nl : 0u;
+    const int li = active ? (int)((uint32_t)item - h * nl) : 0;
+    const HitRec *hr = (const HitRec *)((const char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + h) * Q.hit_stride);
+    // head of the record: P, weight, pixel, prim, material -- four 16-byte pieces fetched together
+    const rec_v2d h0 = rec_load(hr, 0), h1 = rec_load(hr, 1), h3 = rec_load(hr, 3);
+    const d3 Pt = mk3(h0.x, h0.y, h1.x);
+    const double weight = h3.x;
+    const int hit_prim = __double2hiint(h3.y);
+    const bool hit_flat = ((uint32_t)__double2loint(h3.y) & HIT_FLAT) != 0;
+    const d3 lpos = ld3(load_light(P.S, li, true).pos);
+    const uint32_t pixel = (uint32_t)__double2loint(h3.y) & ~HIT_FLAT;
+    bool lit = false;
+    int defer_cam = -1;
+    d3 local = mk3(0, 0, 0);
+    STAMP(3);
+    if (active) {
+        const d3 toL = sub3(lpos, Pt);
+        const d3 rd = unit3(toL);
+        const double maxT = norm3(toL) - .01;
+        bool only = false;
+        int closest = -1;
+        bool occluded;
+        bool order_free = MODE == SHADOW_BVH;
+        if (MODE == SHADOW_HYBRID) {
+            // checkOccluded3 depends on the visiting order only through transparent spheres the ray hits
+            // (Octree.h:1222-1243); a ray that hits none of them is blocked iff it hits anything
+            const double d2 = dot3(rd, rd);
+            order_free = true;
+            for (int k = 0; k < P.S.n_tsph; ++k)
+                if (P.S.tsph_prim[k] != hit_prim && sph_test(&P.S.tsph[k], Pt, rd, d2, .01, maxT) < maxT) order_free = false;
+        }
+        if (order_free) {
+            // no transparent sphere in the way: "occluded" is "any hit", and never "only transparent"
+            const double d2 = dot3(rd, rd);
+            occluded = false;
+            if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
+                const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
+                WC_ADD(wc, rays);
+                occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc) ||
+                           bvh_any<false>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc);
+            }
+        } else if (MODE != SHADOW_BVH) {
+            occluded = trace_shadow(P.S, Pt, rd, hit_prim, maxT, cull, &only, &closest);
+        } else {
+            occluded = false;
+        }
+        if (occluded && only) {
+            // shadowed by transparent spheres only: the light camera of (that sphere, this light)
+            // decides how much light arrives (Camera.h:406-451); evaluated in k_lightcam
+            if (P.lc_mask) P.lc_mask[pixel] = 1;
+            if (P.S.lc_table && closest >= 0) {
+                const int rank = P.S.prim_lc_rank[closest];
+                if (rank >= 0) defer_cam = rank * P.S.n_lights + li;
+            }
+        }
+        lit = !occluded;
+        STAMP(4);
+        if (lit) {
+            const rt_light lgt = load_light(P.S, li, true);     // read again here rather than kept in registers through the walk
+            // the view vector from the record; the two normals from the record too, or from the primitive's table
+            // entry when they are the flat triangle's own -- four 16-byte pieces fetched together
+            const void *nsrc = hit_flat ? (const void *)&P.S.prim_n23[(size_t)hit_prim * 6] : (const void *)hr->n;
+            const rec_v2d g2 = rec_load(hr, 2), n0 = rec_load(nsrc, 0), n1 = rec_load(nsrc, 1), n2 = rec_load(nsrc, 2);
+            const int hit_mat = hit_flat ? P.S.prim_material[hit_prim] : hr->mat;
+            local = phong_terms(load_material(P.S, hit_mat, true), mk3(n0.x, n0.y, n1.x), mk3(n1.y, n2.x, n2.y),
+                                mk3(h1.y, g2.x, g2.y), &lgt, rd, .999999);
+        }
+    }
+    if (MODE != SHADOW_BVH && P.S.lc_table) {
+        bool ok;
+        const bool want = defer_cam >= 0;
+        const uint32_t slot = wave_reserve(want, &Q.counts[CNT_DEFER(Q.generation)], Q.hit_shard_cap, &Q.counts[CNT_OVERFLOW + 1], &ok);
+        if (ok) {
+            HitRec *dr = &Q.deferred[slot];
+            *dr = *hr;
+            dr->pixel = pixel | (hit_flat ? HIT_FLAT : 0u);
+            dr->light = li;
+            dr->cam = defer_cam;
+            if (hit_flat) dr->mat = P.S.prim_material[hit_prim];
+        } else if (want) {   // queue full: evaluate here
+            const double kfac = lc_calc_intensity(P.S.lc_table, defer_cam, Pt);
+            if (kfac > .01) {
+                lit = true;
+                const rt_light lgt = load_light(P.S, li, true);
+                const double *nsrc = hit_flat ? &P.S.prim_n23[(size_t)hit_prim * 6] : hr->n;
+                const int hit_mat = hit_flat ? P.S.prim_material[hit_prim] : hr->mat;
+                local = phong_terms(load_material(P.S, hit_mat, true), ld3(nsrc), ld3(nsrc + 3), ld3(hr->v), &lgt,
+                                    unit3(sub3(lpos, Pt)), kfac);
+            }
+        }
+    }
+    STAMP(5);
+    accum_add_runs(P.accum, active, lit, pixel, weight, local);
+    STAMP(8);
+
+#undef STAMP_SEL
+}
+
 template <int MODE>
 DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
 {
@@ -295,103 +414,7 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
     const bool cull = P.cull_shadow != 0;
     WalkCount wc{};
     for (long long chunk = next_chunk(P.S); chunk < (long long)smap.total; chunk = next_chunk(P.S)) {
-        int shard;
-        const int item = shard_locate(smap, (uint32_t)chunk, &shard);
-        const bool active = item >= 0;
-        const uint32_t h = active ? (uint32_t)item / nl : 0u;
-        const int li = active ? (int)((uint32_t)item - h * nl) : 0;
-        const HitRec *hr = (const HitRec *)((const char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + h) * Q.hit_stride);
-        // head of the record: P, weight, pixel, prim, material -- four 16-byte pieces fetched together
-        const rec_v2d h0 = rec_load(hr, 0), h1 = rec_load(hr, 1), h3 = rec_load(hr, 3);
-        const d3 Pt = mk3(h0.x, h0.y, h1.x);
-        const double weight = h3.x;
-        const int hit_prim = __double2hiint(h3.y);
-        const bool hit_flat = ((uint32_t)__double2loint(h3.y) & HIT_FLAT) != 0;
-        const d3 lpos = ld3(load_light(P.S, li, true).pos);
-        const uint32_t pixel = (uint32_t)__double2loint(h3.y) & ~HIT_FLAT;
-        bool lit = false;
-        int defer_cam = -1;
-        d3 local = mk3(0, 0, 0);
-        STAMP(3);
-        if (active) {
-            const d3 toL = sub3(lpos, Pt);
-            const d3 rd = unit3(toL);
-            const double maxT = norm3(toL) - .01;
-            bool only = false;
-            int closest = -1;
-            bool occluded;
-            bool order_free = MODE == SHADOW_BVH;
-            if (MODE == SHADOW_HYBRID) {
-                // checkOccluded3 depends on the visiting order only through transparent spheres the ray hits
-                // (Octree.h:1222-1243); a ray that hits none of them is blocked iff it hits anything
-                const double d2 = dot3(rd, rd);
-                order_free = true;
-                for (int k = 0; k < P.S.n_tsph; ++k)
-                    if (P.S.tsph_prim[k] != hit_prim && sph_test(&P.S.tsph[k], Pt, rd, d2, .01, maxT) < maxT) order_free = false;
-            }
-            if (order_free) {
-                // no transparent sphere in the way: "occluded" is "any hit", and never "only transparent"
-                const double d2 = dot3(rd, rd);
-                occluded = false;
-                if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
-                    const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
-                    WC_ADD(wc, rays);
-                    occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc) ||
-                               bvh_any<false>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc);
-                }
-            } else if (MODE != SHADOW_BVH) {
-                occluded = trace_shadow(P.S, Pt, rd, hit_prim, maxT, cull, &only, &closest);
-            } else {
-                occluded = false;
-            }
-            if (occluded && only) {
-                // shadowed by transparent spheres only: the light camera of (that sphere, this light)
-                // decides how much light arrives (Camera.h:406-451); evaluated in k_lightcam
-                if (P.lc_mask) P.lc_mask[pixel] = 1;
-                if (P.S.lc_table && closest >= 0) {
-                    const int rank = P.S.prim_lc_rank[closest];
-                    if (rank >= 0) defer_cam = rank * P.S.n_lights + li;
-                }
-            }
-            lit = !occluded;
-            STAMP(4);
-            if (lit) {
-                const rt_light lgt = load_light(P.S, li, true);     // read again here rather than kept in registers through the walk
-                // the view vector from the record; the two normals from the record too, or from the primitive's table
-                // entry when they are the flat triangle's own -- four 16-byte pieces fetched together
-                const void *nsrc = hit_flat ? (const void *)&P.S.prim_n23[(size_t)hit_prim * 6] : (const void *)hr->n;
-                const rec_v2d g2 = rec_load(hr, 2), n0 = rec_load(nsrc, 0), n1 = rec_load(nsrc, 1), n2 = rec_load(nsrc, 2);
-                const int hit_mat = hit_flat ? P.S.prim_material[hit_prim] : hr->mat;
-                local = phong_terms(load_material(P.S, hit_mat, true), mk3(n0.x, n0.y, n1.x), mk3(n1.y, n2.x, n2.y),
-                                    mk3(h1.y, g2.x, g2.y), &lgt, rd, .999999);
-            }
-        }
-        if (MODE != SHADOW_BVH && P.S.lc_table) {
-            bool ok;
-            const bool want = defer_cam >= 0;
-            const uint32_t slot = wave_reserve(want, &Q.counts[CNT_DEFER(Q.generation)], Q.hit_shard_cap, &Q.counts[CNT_OVERFLOW + 1], &ok);
-            if (ok) {
-                HitRec *dr = &Q.deferred[slot];
-                *dr = *hr;
-                dr->pixel = pixel | (hit_flat ? HIT_FLAT : 0u);
-                dr->light = li;
-                dr->cam = defer_cam;
-                if (hit_flat) dr->mat = P.S.prim_material[hit_prim];
-            } else if (want) {   // queue full: evaluate here
-                const double kfac = lc_calc_intensity(P.S.lc_table, defer_cam, Pt);
-                if (kfac > .01) {
-                    lit = true;
-                    const rt_light lgt = load_light(P.S, li, true);
-                    const double *nsrc = hit_flat ? &P.S.prim_n23[(size_t)hit_prim * 6] : hr->n;
-                    const int hit_mat = hit_flat ? P.S.prim_material[hit_prim] : hr->mat;
-                    local = phong_terms(load_material(P.S, hit_mat, true), ld3(nsrc), ld3(nsrc + 3), ld3(hr->v), &lgt,
-                                        unit3(sub3(lpos, Pt)), kfac);
-                }
-            }
-        }
-        STAMP(5);
-        accum_add_runs(P.accum, active, lit, pixel, weight, local);
-        STAMP(8);
+        shadow_chunk<MODE>(P, Q, smap, nl, chunk, stack, cull, wc);
     }
     STAMP(9);
 #ifdef RT_COUNT
@@ -413,6 +436,49 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_shadow_hybrid
     shadow_pass<SHADOW_HYBRID>(P, Q);
 }
 
+
+
+// The shadow pass of generation g and the closest-hit pass of generation g+1 as ONE launch.  Both consume what the
+// closest-hit pass of generation g produced (its hits, its secondary rays) and neither reads what the other writes.
+// A wave first takes shadow chunks from its block's share of that list, then closest-hit chunks from its share of the
+// other (two tickets; the waves of a block move on independently).  A batch then takes 7 launches instead of 12
+// (C0, S0+C1, ..., S4+C5, S5), and every launch that is left out is a ramp (LDS fill, first chunks) and a tail (the last
+// blocks' last chunks) the chip does not idle through.  The two loops follow each other, so the kernel needs the
+// registers of the hungrier one, not of both.
+template <bool BVHC, int MODE>
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_pair(FrameParams P, QueueSet Qs, QueueSet Qc)
+{
+    constexpr bool WITH_NODES = BVHC || MODE != SHADOW_EXACT;
+    int *stack = &s_lds[WITH_NODES ? threadIdx.x : 0];
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t nl = (uint32_t)P.S.n_lights;
+    const long long first_chunk = (long long)blockIdx.x * (blockDim.x >> 6);
+    long long n_s, n_c;
+    {
+        const ShardMap sm_s = shard_map(&Qs.counts[CNT_HITS(Qs.generation)], Qs.hit_shard_cap, nl);
+        const ShardMap sm_c = shard_map(&Qc.counts[CNT_RAYS(Qc.generation)], Qc.in_shard_cap, 1u);
+        n_s = (long long)sm_s.total;
+        n_c = (long long)sm_c.total;
+    }
+    if (first_chunk >= n_s && first_chunk >= n_c) return;
+    fill_node_cache(P.S, WITH_NODES);
+    WalkCount wc{};
+    if (first_chunk < n_s) {
+        const ShardMap smap = shard_map(&Qs.counts[CNT_HITS(Qs.generation)], Qs.hit_shard_cap, nl);
+        const bool cull = P.cull_shadow != 0;
+        for (long long chunk = next_chunk(P.S, 0); chunk < n_s; chunk = next_chunk(P.S, 0))
+            shadow_chunk<MODE>(P, Qs, smap, nl, chunk, stack, cull, wc);
+    }
+    if (first_chunk < n_c) {
+        const ShardMap smap = shard_map(&Qc.counts[CNT_RAYS(Qc.generation)], Qc.in_shard_cap, 1u);
+        const bool cull = P.cull_closest != 0;
+        for (long long chunk = next_chunk(P.S, 1); chunk < n_c; chunk = next_chunk(P.S, 1))
+            closest_chunk<false, BVHC>(P, Qc, smap, chunk, lane, stack, cull, wc);
+    }
+#ifdef RT_COUNT
+    walk_count_flush(wc, 8);
+#endif
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // The whole ray tree of a sample in one launch, for frames too small to fill the chip pass by pass.

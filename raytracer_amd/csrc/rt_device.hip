@@ -77,6 +77,8 @@ struct DebugOptions {
     bool verbose = false;           // device properties, light-camera and splitter statistics on stderr
     int leaf_max = 0, split_budget = -1;   // hierarchy builder (accel::Options), read at the next upload
     int fused = -1;                 // 1: always the one-launch kernel, 0: never, -1: by frame size
+    int overlap = -1;               // 1: shadow passes on the second stream beside the next closest-hit pass, 0: one stream, -1: by batch size
+    int pair = -1;                  // 1: shadow pass g and closest-hit pass g+1 in one launch, 0: a launch each, -1: default (paired)
 };
 
 // ------------------------------------------------------------------ host side
@@ -126,8 +128,9 @@ struct rt_ctx {
     uint32_t pending_flags = 0;
     unsigned long long pending_primaries = 0;
     int pending_batches = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_shadow;
-    size_t ev_closest_used = 0, ev_shadow_used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_shadow, ev_pair;
+    size_t ev_closest_used = 0, ev_shadow_used = 0, ev_pair_used = 0;
+    int pending_closest_per_batch = 6;     // closest-hit launches per batch of the frame in flight (1 when passes are paired)
     int cu_count = 256;
     int32_t n_materials = 0;
     size_t lds_per_cu = 64 * 1024;   // LDS of one compute unit (maxSharedMemoryPerMultiProcessor)
@@ -205,6 +208,8 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
         const void *kernels[] = {(const void *)k_closest<true, true>,  (const void *)k_closest<true, false>, (const void *)k_closest<false, true>,
                                  (const void *)k_closest<false, false>, (const void *)k_shadow<true>,       (const void *)k_shadow<false>,
                                  (const void *)k_shadow_hybrid,
+                                 (const void *)k_pair<true, SHADOW_BVH>, (const void *)k_pair<true, SHADOW_HYBRID>,
+                                 (const void *)k_pair<true, SHADOW_EXACT>, (const void *)k_pair<false, SHADOW_EXACT>,
                                  (const void *)k_fused<true, SHADOW_BVH>, (const void *)k_fused<true, SHADOW_HYBRID>,
                                  (const void *)k_fused<true, SHADOW_EXACT>, (const void *)k_fused<false, SHADOW_EXACT>};
         for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
@@ -244,6 +249,7 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     for (void *p : ctx->stage) (void)hipFree(p);
     for (auto &pr : ctx->ev_closest) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : ctx->ev_shadow) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &pr : ctx->ev_pair) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     (void)hipEventDestroy(ctx->ev_begin);
     (void)hipEventDestroy(ctx->ev_end);
     (void)hipStreamDestroy(ctx->stream);
@@ -983,6 +989,13 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     QueuePlan QP;
     FrameBuffers B;
     bool overlap = false;
+    // Paired passes (k_pair): the shadow pass of a generation and the closest-hit pass of the next one share a launch.
+    // Taken for batches of up to 16 M samples, where a launch's ramp and tail are a large part of it (8K x 16 spp frame
+    // in 16 M batches 81.4 -> 79.1 ms; 512 x 512 frames: teapot-3 0.435 -> 0.389 ms, balls 0.723 -> 0.643, refract
+    // 0.504 -> 0.459, against the two-stream overlap they replace).  Larger batches fill the chip for long enough
+    // that the paired kernel's few extra register spills cost more than the launches it saves (256 M batches: 70.2 -> 73.4 ms).
+    const bool pair_by_size = batch_chunks * 64 <= (1ll << 24);
+    const bool use_pair = !noalloc && !use_fused && P.S.n_lights > 0 && (ctx->dbg.pair == 1 || (ctx->dbg.pair < 0 && pair_by_size));
     long long fused_defer_cap = 0;
     if (use_fused) {
         // no ray or hit queues; only the deferred light-camera queries leave the kernel (when that queue is full they are
@@ -1001,7 +1014,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         B.deferred[0] = ctx->deferred[0];
         B.counts = ctx->counts;
         B.totals = ctx->totals;
-    } else if (local_rows > 0 && !noalloc) {
+        } else if (local_rows > 0 && !noalloc) {
         // Overlap pays when a pass cannot fill the chip by itself (small frames: each pass is one
         // ray's latency long); big batches already saturate it with one persistent grid, and there
         // the extra ordering constraints only cost, so they run on one stream.
@@ -1011,9 +1024,10 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         // The queues of a batch must fit the context's memory budget, and the allocations must succeed: the batch is
         // halved until both hold.
         for (;;) {
-            overlap = batch_chunks * 64 <= (1ll << 22) && block == 256;
+            overlap = !use_pair && batch_chunks * 64 <= (1ll << 22) && block == 256;
+            if (ctx->dbg.overlap >= 0 && !use_pair) overlap = ctx->dbg.overlap != 0;
             plan_queues(QP, batch_chunks, waves_per_block, max_blocks, fan_out, ctx->growth);
-            QP.hit_buffers = overlap ? 4 : 1;
+            QP.hit_buffers = overlap ? 4 : (use_pair ? 2 : 1);
             QP.deferred = use_lightcam;
             const bool smallest = batch_chunks <= spp;
             int rc = RT_OK;
@@ -1068,7 +1082,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     hipStream_t st = ctx->stream;
     HIP_TRY(hipEventRecord(ctx->ev_begin, st));
     HIP_TRY(hipMemsetAsync(B.totals, 0, 16 * sizeof(unsigned long long), st));
-    ctx->ev_closest_used = ctx->ev_shadow_used = 0;
+    ctx->ev_closest_used = ctx->ev_shadow_used = ctx->ev_pair_used = 0;
+    ctx->pending_closest_per_batch = use_pair ? 1 : 6;
     ctx->pending_flags = o->flags;
     ctx->pending_batches = 0;
     ctx->pending_primaries = (unsigned long long)n_pixels * (unsigned long long)(N * N);
@@ -1160,6 +1175,60 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             uint32_t *counts = B.counts + (size_t)par * CNT_WORDS;
             if (batch_no >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[par], 0));
             HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
+            auto queue_set = [&](int g) {
+                QueueSet Q{};
+                Q.rays_in = B.rays[g & 1];
+                Q.rays_out = B.rays[(g + 1) & 1];
+                Q.hits = B.hits[g & 1];
+                Q.deferred = B.deferred[g];
+                Q.counts = counts;
+                Q.in_shard_cap = (uint32_t)ray_cap[g];
+                Q.out_shard_cap = (uint32_t)(g < 5 ? ray_cap[g + 1] : 0);
+                Q.hit_shard_cap = (uint32_t)hit_cap[g];
+                Q.hit_stride = all_flat ? 64u : 128u;
+                Q.generation = g;
+                Q.chunk_begin = t0;
+                Q.chunk_end = t1;
+                Q.block_row0 = (t0 / (N * N)) / P.blocks_x;
+                Q.block_col0 = (int32_t)((t0 / (N * N)) % P.blocks_x);
+                return Q;
+            };
+            if (use_pair) {
+                // C0, then S_g + C_g+1 for g = 0..4, then S5: seven launches on one stream, hit buffers alternating by generation
+                std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+                {
+                    const QueueSet Q = queue_set(0);
+                    if (timing && !(ev = next_event_pair(ctx->ev_closest, ctx->ev_closest_used))) return fail(RT_ERR_DEVICE, "hipEventCreate failed");
+                    if (ev) HIP_TRY(hipEventRecord(ev->first, st));
+                    long long blocks = (t1 - t0 + waves_per_block - 1) / waves_per_block;
+                    if (blocks > blocks0) blocks = blocks0;
+                    if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
+                    else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
+                    if (ev) HIP_TRY(hipEventRecord(ev->second, st));
+                }
+                for (int g = 0; g < 5; ++g) {
+                    const QueueSet Qs = queue_set(g), Qc = queue_set(g + 1);
+                    ev = nullptr;
+                    if (timing && !(ev = next_event_pair(ctx->ev_pair, ctx->ev_pair_used))) return fail(RT_ERR_DEVICE, "hipEventCreate failed");
+                    if (ev) HIP_TRY(hipEventRecord(ev->first, st));
+                    if (!bvh_closest_ok) hipLaunchKernelGGL((k_pair<false, SHADOW_EXACT>), dim3((unsigned)max_blocks), dim3(block), lds_bvh, st, P, Qs, Qc);
+                    else if (bvh_shadow_ok) hipLaunchKernelGGL((k_pair<true, SHADOW_BVH>), dim3((unsigned)max_blocks), dim3(block), lds_bvh, st, P, Qs, Qc);
+                    else if (hybrid_shadow) hipLaunchKernelGGL((k_pair<true, SHADOW_HYBRID>), dim3((unsigned)max_blocks), dim3(block), lds_bvh, st, P, Qs, Qc);
+                    else hipLaunchKernelGGL((k_pair<true, SHADOW_EXACT>), dim3((unsigned)max_blocks), dim3(block), lds_bvh, st, P, Qs, Qc);
+                    if (ev) HIP_TRY(hipEventRecord(ev->second, st));
+                }
+                {
+                    const QueueSet Q = queue_set(5);
+                    ev = nullptr;
+                    if (timing && !(ev = next_event_pair(ctx->ev_shadow, ctx->ev_shadow_used))) return fail(RT_ERR_DEVICE, "hipEventCreate failed");
+                    if (ev) HIP_TRY(hipEventRecord(ev->first, st));
+                    if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(block), lds_shadow, st, P, Q);
+                    else if (hybrid_shadow) hipLaunchKernelGGL(k_shadow_hybrid, dim3((unsigned)max_blocks), dim3(block), lds_shadow, st, P, Q);
+                    else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(block), lds_shadow, st, P, Q);
+                    if (ev) HIP_TRY(hipEventRecord(ev->second, st));
+                }
+                HIP_TRY(hipEventRecord(ctx->ev_c[5], st));
+            } else
             for (int g = 0; g < 6; ++g) {
                 QueueSet Q{};
                 Q.rays_in = B.rays[g & 1];
@@ -1268,7 +1337,7 @@ extern "C" int rt_sync(rt_ctx *ctx, rt_stats *stats)
                 float m = 0;
                 HIP_TRY(hipEventElapsedTime(&m, ctx->ev_closest[i].first, ctx->ev_closest[i].second));
                 c += m;
-                if (ctx->pending_fused || i % 6 == 0) { prim += m; ++prim_n; }      // six closest-hit passes per batch, generation 0 first
+                if (ctx->pending_fused || i % (size_t)ctx->pending_closest_per_batch == 0) { prim += m; ++prim_n; }   // generation 0 first
             }
             stats->primary_ms = prim;
             stats->primary_launches = prim_n;
@@ -1277,9 +1346,17 @@ extern "C" int rt_sync(rt_ctx *ctx, rt_stats *stats)
                 HIP_TRY(hipEventElapsedTime(&m, ctx->ev_shadow[i].first, ctx->ev_shadow[i].second));
                 s += m;
             }
+            double pr = 0;
+            for (size_t i = 0; i < ctx->ev_pair_used; ++i) {
+                float m = 0;
+                HIP_TRY(hipEventElapsedTime(&m, ctx->ev_pair[i].first, ctx->ev_pair[i].second));
+                pr += m;
+            }
+            stats->pair_ms = pr;
+            stats->pair_launches = ctx->ev_pair_used;
             stats->closest_ms = c;
             stats->shadow_ms = s;
-            stats->other_ms = ms - c - s;
+            stats->other_ms = ms - c - s - pr;
             stats->closest_launches = ctx->ev_closest_used;
             stats->shadow_launches = ctx->ev_shadow_used;
         }
@@ -1355,6 +1432,8 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "leaf_max") ctx->dbg.leaf_max = (int)value;
     else if (n == "split_budget") ctx->dbg.split_budget = (int)value;
     else if (n == "fused") ctx->dbg.fused = (int)value;
+    else if (n == "overlap") ctx->dbg.overlap = (int)value;
+    else if (n == "pair") ctx->dbg.pair = (int)value;
     else if (n == "queue_growth") ctx->growth = value < 1 ? 1 : (value > 32 ? 32 : (int)value);
     else return fail(RT_ERR_INVALID, "rt_debug_set_option: unknown option '" + n + "'");
     return RT_OK;

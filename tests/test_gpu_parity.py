@@ -250,6 +250,32 @@ def test_one_launch_kernel_equals_oracle(gpu, oracle_frame, scene, res, kw):
         assert_frames_match(parts[p], o, rows=rt.part_row_indices(cam.resy, 8, 2, p))
 
 
+@pytest.mark.parametrize("scene,res", [("teapot-3", None), ("balls", (300, 300)), ("refract", (300, 300)), ("glass3", (256, 256)),
+                                       ("gears", (160, 160))])
+def test_paired_and_separate_passes_agree(gpu, oracle_frame, scene, res):
+    """Small batches run the shadow pass of a generation and the closest-hit pass of the next in one launch, large
+    ones a launch per pass (on one stream or two): the same frame through all three, and against the oracle."""
+    s = load_scene(gpu, scene)
+    cam = s.camera(*res) if res else s.camera()
+    frames = []
+    for pair, overlap in ((1, -1), (0, 0), (0, 1)):
+        gpu.set_option("pair", pair)
+        gpu.set_option("overlap", overlap)
+        gpu.set_option("fused", 0)
+        try:
+            frames.append(gpu.render(cam, flags=rt.FLAG_KEEP_ZERO_WEIGHT))
+        finally:
+            gpu.set_option("pair", -1)
+            gpu.set_option("overlap", -1)
+            gpu.set_option("fused", -1)
+    o = oracle_frame(scene, res=res)
+    for g in frames:
+        assert_frames_match(g, o, tol=1e-6)
+        assert g["stats"]["closest_rays"] == o["counters"]["closest_rays"]
+        assert g["stats"]["shadow_rays"] == o["counters"]["shadow_rays"]
+        assert np.array_equal(g["lightcam_mask"], o["lightcam_mask"])
+
+
 @pytest.mark.parametrize("scene", ["glass3", "glass"])
 def test_one_launch_kernel_with_light_cameras(gpu, oracle_frame, scene):
     s = load_scene(gpu, scene)
