@@ -125,6 +125,11 @@ _SIGNATURES = {
                                     C.POINTER(Stats)]),
     "rt_noalloc_scratch_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
     "rt_debug_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "rt_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_group_destroy": (C.c_int, [C.c_void_p]),
+    "rt_group_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "rt_group_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "rt_group_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.POINTER(FrameOut), C.POINTER(Stats)]),
     "rt_debug_intersect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.c_double, C.c_double, C.POINTER(C.c_double)]),
     "rth_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -405,6 +410,55 @@ class Renderer:
     def sync(self):
         stats = Stats()
         _check(load().rt_sync(self._ctx, C.byref(stats)))
+        return stats.as_dict()
+
+
+class Group:
+    """Several GPUs of one node behind one render call (rt_group): one context per listed device."""
+
+    def __init__(self, devices):
+        self._g = C.c_void_p()
+        ids = (C.c_int * len(devices))(*devices)
+        _check(load().rt_group_create(ids, len(devices), C.byref(self._g)))
+        self.devices = list(devices)
+
+    def close(self):
+        if self._g:
+            load().rt_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, scene):
+        _check(load().rt_group_upload_scene(self._g, C.byref(scene.desc)))
+
+    def render(self, cam, num_samples=1, aperture=0.0, flags=0, seed=0, band_rows=16,
+               want=("rgb_f64", "rgb_u8", "hit_id", "lightcam_mask")):
+        """Renders the whole frame into host numpy arrays (frame order)."""
+        opts = RenderOpts(num_samples=num_samples, aperture=aperture, flags=flags, seed=seed, band_rows=band_rows, n_parts=1, part=0)
+        bufs = {}
+        out = FrameOut(on_device=0)
+        shapes = {"rgb_f64": ((cam.resy, cam.resx, 3), np.float64), "rgb_u8": ((cam.resy, cam.resx, 3), np.uint8),
+                  "hit_id": ((cam.resy, cam.resx), np.int32), "lightcam_mask": ((cam.resy, cam.resx), np.uint8)}
+        for name in want:
+            shape, dt = shapes[name]
+            bufs[name] = np.zeros(shape, dtype=dt)
+            setattr(out, name, bufs[name].ctypes.data)
+        stats = Stats()
+        _check(load().rt_group_render(self._g, C.byref(cam), C.byref(opts), C.byref(out), C.byref(stats)))
+        bufs["stats"] = stats.as_dict()
+        return bufs
+
+    def render_device(self, cam, rgb_u8_ptr=0, rgb_f64_ptr=0, num_samples=1, aperture=0.0, flags=0, seed=0, band_rows=16):
+        """Renders into frame-order device buffers on the group's first device."""
+        opts = RenderOpts(num_samples=num_samples, aperture=aperture, flags=flags, seed=seed, band_rows=band_rows, n_parts=1, part=0)
+        out = FrameOut(rgb_f64=rgb_f64_ptr or None, rgb_u8=rgb_u8_ptr or None, on_device=1)
+        stats = Stats()
+        _check(load().rt_group_render(self._g, C.byref(cam), C.byref(opts), C.byref(out), C.byref(stats)))
         return stats.as_dict()
 
 

@@ -85,12 +85,16 @@ def build_library(force=False):
         _run([hipcc] + DEVICE_FLAGS + ['-DRT_BUILD_ID="%s"' % sid, "-c", dev_src, "-o", dev_obj])
         with open(id_file, "w") as f:
             f.write(sid + "\n")
+    group_src = os.path.join(CSRC, "rt_group.hip")
+    group_obj = os.path.join(CSRC, "rt_group.o")
+    if force or _newer(group_obj, [group_src, header, os.path.abspath(__file__)]):
+        _run([hipcc] + DEVICE_FLAGS + ["-c", group_src, "-o", group_obj])
     if force or _newer(host_obj, [host_src, header, os.path.join(CSRC, "host_scene.hpp"), os.path.abspath(__file__)]):
         _run(["g++"] + HOST_FLAGS + ["-c", host_src, "-o", host_obj])
     if force or _newer(accel_obj, [accel_src, accel_hdr, header, os.path.abspath(__file__)]):
         _run(["g++"] + HOST_FLAGS + ["-c", accel_src, "-o", accel_obj])
-    if force or _newer(LIB, deps + [dev_obj, host_obj, accel_obj, lc_obj]):
-        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, dev_obj, host_obj, accel_obj, lc_obj])
+    if force or _newer(LIB, deps + [dev_obj, host_obj, accel_obj, lc_obj, group_obj]):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, dev_obj, host_obj, accel_obj, lc_obj, group_obj, "-lpthread"])
     return LIB
 
 

@@ -94,7 +94,7 @@ DEV void fill_node_cache(const DevScene &S, bool with_nodes)
     glb_v4i *lsrc = (glb_v4i *)S.lights;
     for (int i = (int)threadIdx.x; i < mpieces + lpieces; i += (int)blockDim.x)
         *(lds_v4i *)(lds + (S.lds_table_word + i * 4)) = i < mpieces ? msrc[i] : lsrc[i - mpieces];
-    if (threadIdx.x == 0) { s_lds[S.lds_ticket_word] = 0; s_lds[S.lds_ticket_word + 1] = 0; }
+    if (threadIdx.x == 0) s_lds[S.lds_ticket_word] = 0;
     __syncthreads();
 }
 
@@ -103,11 +103,10 @@ DEV void fill_node_cache(const DevScene &S, bool with_nodes)
 // waves draw the chunks one at a time from a ticket in LDS instead of in a fixed stride, so that all waves of
 // a block finish within a chunk of each other: a block keeps its LDS and its wave slots until its last wave
 // is done, and with a fixed stride the other waves' slots idled a quarter of the time.
-// (`list` selects one of the block's two tickets: a kernel that works through two lists one after the other uses both.)
-DEV long long next_chunk(const DevScene &S, int list = 0)
+DEV long long next_chunk(const DevScene &S)
 {
     int t = 0;
-    if ((threadIdx.x & 63) == 0) t = atomicAdd(&s_lds[S.lds_ticket_word + list], 1);
+    if ((threadIdx.x & 63) == 0) t = atomicAdd(&s_lds[S.lds_ticket_word], 1);
     t = __builtin_amdgcn_readfirstlane(t);
     const int shift = S.stack_shift - 6;          // log2 of the waves per block
     return (((long long)blockIdx.x + (long long)gridDim.x * (t >> shift)) << shift) + (t & ((1 << shift) - 1));

@@ -1,0 +1,233 @@
+// Several GPUs of one node behind one call: the multi-GPU form of the render boundary.
+//
+// The reference splits a frame over two host threads by interleaving rows (Driver.cpp:377, 735-769).  Here the frame
+// is cut into bands of `band_rows` rows dealt round-robin to the members of a group (band b -> member b % N), every
+// member is an rt_ctx on its own GPU with the scene replicated, and one host thread per member renders its part into a
+// compact buffer on its device.  The only exchange is the end-of-frame gather: each compact buffer goes to the first
+// member's device with one peer copy over xGMI (every peer has its own link to that device, so the copies run side by
+// side), and one kernel per output puts the rows into frame order.  No collective library is involved: a gather to one
+// root over point-to-point links is N-1 independent copies.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/raytracer_amd.h"
+
+extern "C" void rt_set_error_string(const char *msg);
+
+namespace {
+int gfail(int code, const std::string &msg)
+{
+    rt_set_error_string(msg.c_str());
+    return code;
+}
+#define GHIP(expr)                                                                                  \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return gfail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// Rows of one part, compact and ascending, into their places in the frame: band b of the part is band
+// (b * n_parts + part) of the frame.  One block per row; whole words when the row allows it.
+__global__ void k_place_rows(const unsigned char *src, unsigned char *dst, int rows, long long row_bytes, int band_rows, int n_parts, int part)
+{
+    const int r = (int)blockIdx.x;
+    if (r >= rows) return;
+    const int band = r / band_rows, within = r - band * band_rows;
+    const long long grow = (long long)(band * n_parts + part) * band_rows + within;
+    const unsigned char *s = src + (long long)r * row_bytes;
+    unsigned char *d = dst + grow * row_bytes;
+    if ((row_bytes & 3) == 0 && (((unsigned long long)s | (unsigned long long)d) & 3ull) == 0) {
+        const unsigned int *s4 = (const unsigned int *)s;
+        unsigned int *d4 = (unsigned int *)d;
+        for (long long i = threadIdx.x; i < row_bytes / 4; i += blockDim.x) d4[i] = s4[i];
+    } else {
+        for (long long i = threadIdx.x; i < row_bytes; i += blockDim.x) d[i] = s[i];
+    }
+}
+
+struct Buffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int device = -1;
+    int ensure(int dev, size_t want)
+    {
+        if (ptr && bytes >= want && device == dev) return RT_OK;
+        GHIP(hipSetDevice(dev));
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; bytes = 0; device = dev;
+        GHIP(hipMalloc(&ptr, want ? want : 1));
+        bytes = want;
+        return RT_OK;
+    }
+    void release()
+    {
+        if (ptr) { (void)hipSetDevice(device); (void)hipFree(ptr); }
+        ptr = nullptr; bytes = 0;
+    }
+};
+}  // namespace
+
+struct rt_group {
+    std::vector<int> devices;
+    std::vector<rt_ctx *> ctx;
+    hipStream_t stream = nullptr;                 // on the first member's device: peer copies and row placement
+    // per member and output kind (f64, u8, hit id, mask): the part on the member's device, and its copy on the first device
+    std::vector<Buffer> part[4], staged[4];
+    Buffer frame[4];                              // frame-order outputs on the first device when the caller's buffers are host memory
+};
+
+static const size_t kPixelBytes[4] = {3 * sizeof(double), 3, sizeof(int32_t), 1};
+
+extern "C" int rt_group_destroy(rt_group *g)
+{
+    if (!g) return RT_OK;
+    for (rt_ctx *c : g->ctx) (void)rt_destroy(c);
+    for (int k = 0; k < 4; ++k) {
+        for (Buffer &b : g->part[k]) b.release();
+        for (Buffer &b : g->staged[k]) b.release();
+        g->frame[k].release();
+    }
+    if (g->stream) { (void)hipSetDevice(g->devices[0]); (void)hipStreamDestroy(g->stream); }
+    delete g;
+    return RT_OK;
+}
+
+extern "C" int rt_group_create(const int *device_ids, int n, rt_group **out)
+{
+    if (!device_ids || n < 1 || n > 64 || !out) return gfail(RT_ERR_INVALID, "rt_group_create: bad argument");
+    rt_group *g = new rt_group();
+    g->devices.assign(device_ids, device_ids + n);
+    for (int i = 0; i < n; ++i) {
+        rt_ctx *c = nullptr;
+        int rc = rt_create(device_ids[i], &c);
+        if (rc != RT_OK) { rt_group_destroy(g); return rc; }
+        g->ctx.push_back(c);
+    }
+    for (int k = 0; k < 4; ++k) { g->part[k].resize(n); g->staged[k].resize(n); }
+    if (hipSetDevice(device_ids[0]) != hipSuccess || hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) {
+        rt_group_destroy(g);
+        return gfail(RT_ERR_DEVICE, "rt_group_create: no stream on the first device");
+    }
+    // direct copies between the members' devices and the first one (ignored where a pair is the same device or already enabled)
+    for (int i = 1; i < n; ++i) {
+        if (device_ids[i] == device_ids[0]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[i]) == hipSuccess && can) {
+            (void)hipSetDevice(device_ids[0]);
+            (void)hipDeviceEnablePeerAccess(device_ids[i], 0);
+            (void)hipGetLastError();
+        }
+    }
+    *out = g;
+    return RT_OK;
+}
+
+extern "C" int rt_group_size(const rt_group *g, int *n)
+{
+    if (!g || !n) return gfail(RT_ERR_INVALID, "rt_group_size: null argument");
+    *n = (int)g->ctx.size();
+    return RT_OK;
+}
+
+// Runs fn(member) on one host thread per member and returns the first failure (its message becomes the caller's).
+template <typename F>
+static int for_each_member(rt_group *g, F fn)
+{
+    const size_t n = g->ctx.size();
+    std::vector<int> rc(n, RT_OK);
+    std::vector<std::string> msg(n);
+    auto body = [&](size_t i) {
+        rc[i] = fn(i);
+        if (rc[i] != RT_OK) msg[i] = rt_last_error();
+    };
+    if (n == 1) body(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < n; ++i) th.emplace_back(body, i);
+        for (std::thread &t : th) t.join();
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (rc[i] != RT_OK) return gfail(rc[i], "member " + std::to_string(i) + " (device " + std::to_string(g->devices[i]) + "): " + msg[i]);
+    return RT_OK;
+}
+
+extern "C" int rt_group_upload_scene(rt_group *g, const rt_scene_desc *scene)
+{
+    if (!g || !scene) return gfail(RT_ERR_INVALID, "rt_group_upload_scene: null argument");
+    return for_each_member(g, [&](size_t i) { return rt_upload_scene(g->ctx[i], scene); });
+}
+
+extern "C" int rt_group_render(rt_group *g, const rt_camera *cam, const rt_render_opts *opts, const rt_frame_out *out, rt_stats *stats)
+{
+    if (!g || !cam || !opts || !out) return gfail(RT_ERR_INVALID, "rt_group_render: null argument");
+    if (cam->resx <= 0 || cam->resy <= 0) return gfail(RT_ERR_INVALID, "rt_group_render: empty frame");
+    const int n = (int)g->ctx.size();
+    const int band = opts->band_rows > 0 ? opts->band_rows : 16;
+    void *dst[4] = {out->rgb_f64, out->rgb_u8, out->hit_id, out->lightcam_mask};
+    std::vector<int32_t> rows((size_t)n, 0);
+    std::vector<rt_render_opts> mo((size_t)n, *opts);
+    for (int i = 0; i < n; ++i) {
+        mo[i].band_rows = band; mo[i].n_parts = n; mo[i].part = i;
+        int rc = rt_part_rows(cam, &mo[i], &rows[i]);
+        if (rc != RT_OK) return rc;
+        for (int k = 0; k < 4; ++k)
+            if (dst[k] && (rc = g->part[k][i].ensure(g->devices[i], (size_t)rows[i] * cam->resx * kPixelBytes[k])) != RT_OK) return rc;
+    }
+    // every member renders its part on a host thread of its own
+    std::vector<rt_stats> ms((size_t)n);
+    int rc = for_each_member(g, [&](size_t i) {
+        rt_frame_out po = {};
+        po.rgb_f64 = dst[0] ? g->part[0][i].ptr : nullptr;
+        po.rgb_u8 = dst[1] ? g->part[1][i].ptr : nullptr;
+        po.hit_id = dst[2] ? g->part[2][i].ptr : nullptr;
+        po.lightcam_mask = dst[3] ? g->part[3][i].ptr : nullptr;
+        po.on_device = 1;
+        return rt_render(g->ctx[i], cam, &mo[i], &po, &ms[i]);
+    });
+    if (rc != RT_OK) return rc;
+    // gather on the first device: one peer copy per member and output, then the rows into frame order
+    const int d0 = g->devices[0];
+    GHIP(hipSetDevice(d0));
+    for (int k = 0; k < 4; ++k) {
+        if (!dst[k]) continue;
+        const size_t row_bytes = (size_t)cam->resx * kPixelBytes[k];
+        unsigned char *frame = static_cast<unsigned char *>(dst[k]);
+        if (!out->on_device) {
+            if ((rc = g->frame[k].ensure(d0, (size_t)cam->resy * row_bytes)) != RT_OK) return rc;
+            frame = static_cast<unsigned char *>(g->frame[k].ptr);
+        }
+        for (int i = 0; i < n; ++i) {
+            if (rows[i] == 0) continue;
+            const unsigned char *src = static_cast<const unsigned char *>(g->part[k][i].ptr);
+            if (g->devices[i] != d0) {
+                if ((rc = g->staged[k][i].ensure(d0, (size_t)rows[i] * row_bytes)) != RT_OK) return rc;
+                GHIP(hipMemcpyPeerAsync(g->staged[k][i].ptr, d0, g->part[k][i].ptr, g->devices[i], (size_t)rows[i] * row_bytes, g->stream));
+                src = static_cast<const unsigned char *>(g->staged[k][i].ptr);
+            }
+            hipLaunchKernelGGL(k_place_rows, dim3((unsigned)rows[i]), dim3(256), 0, g->stream, src, frame, rows[i], (long long)row_bytes, band, n, i);
+        }
+        GHIP(hipGetLastError());
+        if (!out->on_device) GHIP(hipMemcpyAsync(dst[k], frame, (size_t)cam->resy * row_bytes, hipMemcpyDeviceToHost, g->stream));
+    }
+    GHIP(hipStreamSynchronize(g->stream));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        for (int i = 0; i < n; ++i) {
+            stats->closest_rays += ms[i].closest_rays;
+            stats->shadow_rays += ms[i].shadow_rays;
+            for (int q = 0; q < 6; ++q) { stats->rays_per_generation[q] += ms[i].rays_per_generation[q]; stats->hits_per_generation[q] += ms[i].hits_per_generation[q]; }
+            if (ms[i].gpu_ms > stats->gpu_ms) stats->gpu_ms = ms[i].gpu_ms;       // the members run side by side
+            stats->closest_ms += ms[i].closest_ms; stats->shadow_ms += ms[i].shadow_ms; stats->pair_ms += ms[i].pair_ms;
+            stats->closest_launches += ms[i].closest_launches; stats->shadow_launches += ms[i].shadow_launches;
+            stats->pair_launches += ms[i].pair_launches;
+            stats->batches += ms[i].batches;
+            stats->queue_overflow |= ms[i].queue_overflow;
+        }
+        stats->lightcam_rays = ms[0].lightcam_rays;      // every member builds the same light cameras
+    }
+    return RT_OK;
+}

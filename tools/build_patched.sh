@@ -17,5 +17,5 @@ $L/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $W/dev_patched.s
 $L/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $W/dev.co $W/dev.o
 $L/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 -input=/dev/null -input=$W/dev.co -output=$W/dev.hipfb
 /opt/rocm/bin/hipcc $FLAGS --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang $W/dev.hipfb -c $C/rt_device.hip -o $W/rt_device.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_variants/lib_$name.so $W/rt_device.o $C/host_scene.o $C/accel_build.o $C/lightcam_build.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_variants/lib_$name.so $W/rt_device.o $C/host_scene.o $C/accel_build.o $C/lightcam_build.o $C/rt_group.o
 echo built build_variants/lib_$name.so
