@@ -28,6 +28,8 @@
 #include "accel_build.hpp"
 #include "lightcam_build.hpp"
 #include "render_kernels.hpp"
+#include "lightcam_device.hpp"
+#include <hipcub/hipcub.hpp>
 
 // ------------------------------------------------------------------ errors
 namespace {
@@ -76,6 +78,7 @@ struct DebugOptions {
     int rounds = 0;                 // rounds of resident blocks a queued pass is cut into (default 2)
     bool verbose = false;           // device properties, light-camera and splitter statistics on stderr
     int leaf_max = 0, split_budget = -1;   // hierarchy builder (accel::Options), read at the next upload
+    int lightcam_host = 0;          // 1: the light cameras' point octrees are built by the host builder (lightcam_build.cpp)
     int fused = -1;                 // 1: always the one-launch kernel, 0: never, -1: by frame size
     int overlap = -1;               // 1: shadow passes on the second stream beside the next closest-hit pass, 0: one stream, -1: by batch size
     int pair = -1;                  // 1: shadow pass g and closest-hit pass g+1 in one launch, 0: a launch each, -1: default (paired)
@@ -102,6 +105,7 @@ struct rt_ctx {
     std::vector<rt_light> h_lights;
     std::vector<std::array<double, 4>> h_lc_spheres;   // centre + radius of every transparent sphere, by rank
     std::vector<void *> lc_allocs;
+    void *lc_ws = nullptr; size_t lc_ws_bytes = 0;     // workspace of the device-side tree builder (grow-only)
     bool lc_built = false;
     uint32_t lc_built_flags = 0;
     unsigned long long lc_rays = 0;
@@ -246,6 +250,7 @@ extern "C" int rt_destroy(rt_ctx *ctx)
 
     (void)hipFree(ctx->counts);
     (void)hipFree(ctx->totals);
+    (void)hipFree(ctx->lc_ws);
     for (void *p : ctx->stage) (void)hipFree(p);
     for (auto &pr : ctx->ev_closest) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : ctx->ev_shadow) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -531,6 +536,99 @@ static std::pair<hipEvent_t, hipEvent_t> *next_event_pair(std::vector<std::pair<
     return &v[used++];
 }
 
+// ------------------------------------------------------------------ light cameras: point octree on the device
+// Builds the point octree of one light camera from its packed impacts (lightcam_device.hpp) on stream `st`.
+// `d_pts` (n_pts points, ray order) is consumed; on success *nodes_out / *points_out are exact-size allocations the
+// caller owns.  Returns RT_ERR_CAPACITY when the node array of the workspace is too small (the caller then takes the
+// host builder).
+static int build_tree_on_device(rt_ctx *ctx, hipStream_t st, const lightcam::Point *d_pts, int n_pts, const unsigned long long *d_max_bits,
+                                void **nodes_out, int32_t *n_nodes_out, void **points_out, int *levels_out)
+{
+    *nodes_out = *points_out = nullptr;
+    *n_nodes_out = 0;
+    const size_t n = (size_t)(n_pts > 0 ? n_pts : 1);
+    const size_t cap = 2 * n + 1024;                      // nodes; a tree has about 0.4 nodes per point
+    int key_bits = 5;
+    while (((size_t)1 << (key_bits - 4)) < n + 1 && key_bits < 60) ++key_bits;
+    size_t sort_bytes = 0;
+    {
+        hipcub::DoubleBuffer<unsigned long long> dk(nullptr, nullptr);
+        hipcub::DoubleBuffer<uint32_t> dv(nullptr, nullptr);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, dk, dv, (int)n, 0, key_bits, st));
+    }
+    // workspace layout
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_pts = take(n * sizeof(lightcam::Point)), o_key0 = take(n * 8), o_key1 = take(n * 8), o_idx0 = take(n * 4),
+                 o_idx1 = take(n * 4), o_own0 = take(n * 4), o_own1 = take(n * 4), o_nodes = take(cap * sizeof(lightcam::Node)),
+                 o_runs = take(cap * 9 * 4), o_sub = take(cap), o_act0 = take(cap * 4), o_act1 = take(cap * 4),
+                 o_ctr = take(sizeof(lcdev::LevelCounters)), o_flag = take(4), o_sort = take(sort_bytes);
+    if (ctx->lc_ws_bytes < off) {
+        if (ctx->lc_ws) HIP_TRY(hipFree(ctx->lc_ws));
+        ctx->lc_ws = nullptr; ctx->lc_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->lc_ws, off));
+        ctx->lc_ws_bytes = off;
+    }
+    unsigned char *ws = static_cast<unsigned char *>(ctx->lc_ws);
+    lightcam::Point *pts[2] = {const_cast<lightcam::Point *>(d_pts), reinterpret_cast<lightcam::Point *>(ws + o_pts)};
+    unsigned long long *key[2] = {reinterpret_cast<unsigned long long *>(ws + o_key0), reinterpret_cast<unsigned long long *>(ws + o_key1)};
+    uint32_t *idx[2] = {reinterpret_cast<uint32_t *>(ws + o_idx0), reinterpret_cast<uint32_t *>(ws + o_idx1)};
+    int32_t *owner[2] = {reinterpret_cast<int32_t *>(ws + o_own0), reinterpret_cast<int32_t *>(ws + o_own1)};
+    lightcam::Node *nodes = reinterpret_cast<lightcam::Node *>(ws + o_nodes);
+    int32_t *runs = reinterpret_cast<int32_t *>(ws + o_runs);
+    uint8_t *subdiv = ws + o_sub;
+    int32_t *active[2] = {reinterpret_cast<int32_t *>(ws + o_act0), reinterpret_cast<int32_t *>(ws + o_act1)};
+    lcdev::LevelCounters *ctr = reinterpret_cast<lcdev::LevelCounters *>(ws + o_ctr);
+    int32_t *flag = reinterpret_cast<int32_t *>(ws + o_flag);
+    void *sort_ws = ws + o_sort;
+
+    const unsigned pb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(lcdev::k_root, dim3(1), dim3(64), 0, st, nodes, d_max_bits, n_pts, flag, ctr, active[0]);
+    hipLaunchKernelGGL(lcdev::k_fill_owner, dim3(pb), dim3(256), 0, st, owner[0], n_pts, flag);
+    lcdev::LevelCounters h{};
+    HIP_TRY(hipMemcpyAsync(&h, ctr, sizeof h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int cur = 0, levels = 0;        // pts[cur], owner[cur], active[cur] are the current level's
+    while (h.n_next > 0) {
+        const int n_active = h.n_next;
+        if ((size_t)h.n_nodes + 8 * (size_t)n_active > cap) return fail(RT_ERR_CAPACITY, "light-camera tree: node workspace too small");
+        hipLaunchKernelGGL(lcdev::k_clear_runs, dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, active[cur], n_active, runs, ctr);
+        hipLaunchKernelGGL(lcdev::k_classify, dim3(pb), dim3(256), 0, st, pts[cur], owner[cur], nodes, n_pts, key[0], idx[0]);
+        hipcub::DoubleBuffer<unsigned long long> dk(key[0], key[1]);
+        hipcub::DoubleBuffer<uint32_t> dv(idx[0], idx[1]);
+        size_t sb = sort_bytes;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_ws, sb, dk, dv, n_pts, 0, key_bits, st));
+        const unsigned long long *key_sorted = dk.Current();
+        hipLaunchKernelGGL(lcdev::k_gather, dim3(pb), dim3(256), 0, st, pts[cur], owner[cur], key_sorted, dv.Current(), n_pts, pts[cur ^ 1],
+                           owner[cur ^ 1], runs);
+        hipLaunchKernelGGL(lcdev::k_children, dim3((unsigned)((n_active + 63) / 64)), dim3(64), 0, st, nodes, (int)cap, active[cur], n_active, runs,
+                           ctr, active[cur ^ 1], subdiv);
+        hipLaunchKernelGGL(lcdev::k_next_owner, dim3(pb), dim3(256), 0, st, key_sorted, owner[cur ^ 1], nodes, subdiv, n_pts);
+        HIP_TRY(hipMemcpyAsync(&h, ctr, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h.overflow) return fail(RT_ERR_CAPACITY, "light-camera tree: node workspace too small");
+        cur ^= 1;
+        if (++levels > 80) return fail(RT_ERR_DEVICE, "light-camera tree: the build does not terminate");
+    }
+    hipLaunchKernelGGL(lcdev::k_finish_nodes, dim3((unsigned)(h.n_nodes < 1024 ? (h.n_nodes + 3) / 4 : 1024)), dim3(256), 0, st, nodes, h.n_nodes,
+                       pts[cur]);
+    HIP_TRY(hipGetLastError());
+    void *dn = nullptr, *dp = nullptr;
+    HIP_TRY(hipMalloc(&dn, sizeof(lightcam::Node) * (size_t)h.n_nodes));
+    if (hipMalloc(&dp, sizeof(lightcam::Point) * n) != hipSuccess) { (void)hipFree(dn); return fail(RT_ERR_DEVICE, "hipMalloc failed for a light-camera tree"); }
+    if (hipMemcpyAsync(dn, nodes, sizeof(lightcam::Node) * (size_t)h.n_nodes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(dp, pts[cur], sizeof(lightcam::Point) * (size_t)n_pts, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipFree(dn); (void)hipFree(dp);
+        return fail(RT_ERR_DEVICE, "light-camera tree: copy out of the workspace failed");
+    }
+    *nodes_out = dn;
+    *points_out = dp;
+    *n_nodes_out = h.n_nodes;
+    if (levels_out) *levels_out = levels;
+    return RT_OK;
+}
+
 // Builds the light camera of every (transparent sphere, light) pair: photon pass on the device,
 // point octree on the host (lightcam_build.cpp), flattened tree back to the device.  The reference
 // creates a camera the first time a shading point needs it (Camera.h:417-440); a camera depends
@@ -572,6 +670,16 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
         (void)hipFree(d_counts);
         return fail(RT_ERR_DEVICE, "hipMalloc failed for the light-camera offsets");
     }
+    // device path: 16 bytes of counters (castLightRay calls, largest |impact|), the impact counts as words, scan workspace
+    unsigned char *d_meta_raw = nullptr;
+    size_t scan_bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_rays, ctx->stream);
+    if (hipMalloc((void **)&d_meta_raw, 256 + n_rays * sizeof(uint32_t) + 256 + scan_bytes) != hipSuccess) {
+        (void)hipFree(d_slots); (void)hipFree(d_counts); (void)hipFree(d_offsets);
+        return fail(RT_ERR_DEVICE, "hipMalloc failed for the light-camera workspace");
+    }
+    uint32_t *d_meta = reinterpret_cast<uint32_t *>(d_meta_raw);          // words 0..3: the two counters; from word 64: the counts
+    void *d_scan_ws = d_meta_raw + 256 + ((n_rays * sizeof(uint32_t) + 255) & ~(size_t)255);
     std::vector<uint32_t> h_offsets(n_rays);
     std::vector<int32_t> h_counts(n_rays);
     std::vector<DevLightCam> table(n_pairs);
@@ -607,6 +715,51 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
             Q.slots = d_slots;
             Q.counts = d_counts;
             hipLaunchKernelGGL(k_photons, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, ctx->stream, Q);
+            if (!ctx->dbg.lightcam_host) {
+                // everything stays on the device: offsets by a prefix sum, the impacts packed in ray order, the tree built
+                // level by level (lightcam_device.hpp); the host reads back a few words per level
+                hipStream_t st = ctx->stream;
+                const unsigned rb = (unsigned)((n_rays + 255) / 256);
+                uint32_t *d_cnt32 = d_meta + 64;
+                hipLaunchKernelGGL(lcdev::k_impact_counts, dim3(rb), dim3(256), 0, st, d_counts, (int)n_rays, d_cnt32);
+                size_t sb = scan_bytes;
+                bool ok = hipcub::DeviceScan::ExclusiveSum(d_scan_ws, sb, d_cnt32, d_offsets, (int)n_rays, st) == hipSuccess;
+                uint32_t last_off = 0, last_cnt = 0;
+                ok = ok && hipMemcpyAsync(&last_off, d_offsets + (n_rays - 1), 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                     hipMemcpyAsync(&last_cnt, d_cnt32 + (n_rays - 1), 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                     hipMemsetAsync(d_meta, 0, 16, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+                if (!ok) { rc = fail(RT_ERR_DEVICE, "light-camera photon pass failed"); break; }
+                const size_t n_pts = (size_t)last_off + last_cnt;
+                if (n_pts >= ((size_t)1 << 31)) { rc = fail(RT_ERR_CAPACITY, "light camera with more than 2^31 impacts"); break; }
+                lightcam::Point *d_packed = nullptr;
+                if (hipMalloc((void **)&d_packed, (n_pts ? n_pts : 1) * sizeof(lightcam::Point)) != hipSuccess) {
+                    rc = fail(RT_ERR_DEVICE, "hipMalloc failed for a light camera's impacts");
+                    break;
+                }
+                hipLaunchKernelGGL(lcdev::k_pack_photons, dim3(rb), dim3(256), 0, st, d_slots, d_counts, d_offsets, (int)n_rays, LC_MAX_IMPACTS, d_packed,
+                                   reinterpret_cast<unsigned long long *>(d_meta), reinterpret_cast<unsigned long long *>(d_meta) + 1);
+                void *dn = nullptr, *dp = nullptr;
+                int32_t n_nodes = 0;
+                int levels = 0;
+                int trc = build_tree_on_device(ctx, st, d_packed, (int)n_pts, reinterpret_cast<unsigned long long *>(d_meta) + 1, &dn, &n_nodes, &dp, &levels);
+                unsigned long long calls = 0;
+                if (trc == RT_OK && hipMemcpy(&calls, d_meta, 8, hipMemcpyDeviceToHost) != hipSuccess) trc = fail(RT_ERR_DEVICE, "light-camera readback failed");
+                (void)hipFree(d_packed);
+                if (trc != RT_OK) { if (dn) (void)hipFree(dn); if (dp) (void)hipFree(dp); rc = trc; break; }
+                ctx->lc_rays += calls;
+                ctx->lc_allocs.push_back(dn);
+                ctx->lc_allocs.push_back(dp);
+                DevLightCam cam{};
+                cam.nodes = static_cast<const lightcam::Node *>(dn);
+                cam.points = static_cast<const lightcam::Point *>(dp);
+                cam.n_nodes = n_nodes;
+                cam.n_points = (int32_t)n_pts;
+                cam.spw = fr.pix_width / N;
+                for (int c = 0; c < 3; ++c) { cam.light_pos[c] = lt.pos[c]; cam.sphere_pos[c] = spos[c]; }
+                table[pair] = cam;
+                if (ctx->dbg.verbose) fprintf(stderr, "[rt] light camera %zu: %zu impacts, %d nodes, %d levels (built on the device)\n", pair, n_pts, n_nodes, levels);
+                continue;
+            }
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
                 hipMemcpy(h_counts.data(), d_counts, n_rays * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
                 rc = fail(RT_ERR_DEVICE, "light-camera photon pass failed");
@@ -654,7 +807,7 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
             build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
         if (rc != RT_OK) break;
-        for (size_t k = 0; k < last - first && rc == RT_OK; ++k) {
+        for (size_t k = 0; ctx->dbg.lightcam_host && k < last - first && rc == RT_OK; ++k) {
             const lightcam::Tree &tree = work[k].tree;
             DevLightCam cam{};
             void *dn = nullptr, *dp = nullptr;
@@ -683,6 +836,7 @@ static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
     (void)hipFree(d_slots);
     (void)hipFree(d_counts);
     (void)hipFree(d_offsets);
+    (void)hipFree(d_meta_raw);
     if (ctx->dbg.verbose) fprintf(stderr, "[rt] %zu light-camera trees: %.1f ms waiting for the host threads after the photon passes\n", n_pairs, build_ms);
     if (rc != RT_OK) { free_lightcams(ctx); return rc; }
     void *dt = nullptr;
@@ -1431,6 +1585,7 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "verbose") ctx->dbg.verbose = value != 0;
     else if (n == "leaf_max") ctx->dbg.leaf_max = (int)value;
     else if (n == "split_budget") ctx->dbg.split_budget = (int)value;
+    else if (n == "lightcam_host") { ctx->dbg.lightcam_host = (int)value; ctx->lc_built = false; }
     else if (n == "fused") ctx->dbg.fused = (int)value;
     else if (n == "overlap") ctx->dbg.overlap = (int)value;
     else if (n == "pair") ctx->dbg.pair = (int)value;
