@@ -71,13 +71,15 @@ struct DevScene {
     const rt_sph_rec *tsph;               // the transparent spheres, by rank, and their primitive ids: the only
     const int32_t *tsph_prim;             //   primitives that make a shadow query depend on the visiting order
     int32_t n_tsph;
-    const struct DevLightCam *lc_table;   // null until the cameras are built
+    const struct DevLightCam *lc_table;   // one entry per pair (n_nodes == 0: that camera is not built yet); null when the term is off
+    uint32_t *lc_needed;                  // per pair: set by the shading passes when a point needs that camera
 };
 
 struct DevLightCam {
-    const lightcam::Node *nodes;
-    const lightcam::Point *points;
-    int32_t n_nodes, n_points;
+    const lightcam::Node *nodes;          // node and point arrays are shared by the cameras that were built together:
+    const lightcam::Point *points;        // `root` is this camera's root in `nodes`, node ranges index `points`
+    int32_t n_nodes, n_points;            // (n_nodes: of the shared array; 0 = camera not built)
+    int32_t root, _pad;
     double spw;                           // sub-pixel width of the light camera (LightCam.h:223)
     double light_pos[3], sphere_pos[3];
 };
@@ -141,6 +143,7 @@ struct QueueSet {
     HitRec *deferred;            // light-camera evaluations postponed by the shadow pass (same shard size as hits)
     uint32_t *counts;
     uint32_t in_shard_cap, out_shard_cap, hit_shard_cap;   // records per shard
+    uint32_t defer_shard_cap;    // ... of the deferred queue: hit_shard_cap times the number of lights
     uint32_t hit_stride;         // bytes from one hit record to the next: 128, or 64 when every hit of the scene is a flat triangle's
     int32_t generation;
     int64_t chunk_begin, chunk_end;  // PRIMARY only: 64-sample chunks of the primary ordering; a batch begins at a

@@ -34,8 +34,8 @@ struct LevelCounters {
 // largest |p| (sqrt((x*x + y*y) + z*z), the reference vector library's association), kept as the bit pattern of a
 // non-negative double, which orders like the number itself.
 __global__ __launch_bounds__(256) void k_pack_photons(const lightcam::Point *slots, const int32_t *counts, const uint32_t *offsets, int n_rays,
-                                                      int slots_per_ray, lightcam::Point *out, unsigned long long *calls,
-                                                      unsigned long long *max_dist_bits)
+                                                      int slots_per_ray, lightcam::Point *out, unsigned long long *max_dist_bits,
+                                                      unsigned long long *calls)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     unsigned long long my_calls = 0;
@@ -68,36 +68,43 @@ __global__ __launch_bounds__(256) void k_impact_counts(const int32_t *counts, in
     if (i < n_rays) out[i] = (uint32_t)(counts[i] & 0xff);
 }
 
-__global__ void k_root(lightcam::Node *nodes, const unsigned long long *max_dist_bits, int n_points, int32_t *owner_of_root_flag,
-                       LevelCounters *ctr, int32_t *active_list)
+// The roots of the trees that are built together: tree t owns points [begins[t], begins[t+1]) of the shared array and is
+// node t of the shared node array.  Cube centred on the origin with side 2 * (largest |impact|) + 1 (LightCam.h:312,325).
+__global__ void k_roots(lightcam::Node *nodes, const unsigned long long *max_dist_bits /* stride 2 words */, const int32_t *begins, int n_trees,
+                        uint8_t *subdivides, LevelCounters *ctr, int32_t *active_list)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double max_dist = __longlong_as_double((long long)*max_dist_bits);
-    const double size = max_dist * 2 + 1;                  // LightCam.h:312,325
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= n_trees) return;
+    const double max_dist = __longlong_as_double((long long)max_dist_bits[2 * t]);
+    const double size = max_dist * 2 + 1;
     const double lo = 0 - size / 2;
     lightcam::Node nd;
     nd.size = size;
     nd.cx = lo + size / 2; nd.cy = lo + size / 2; nd.cz = lo + size / 2;
-    nd.begin = 0; nd.end = n_points;
+    nd.begin = begins[t]; nd.end = begins[t + 1];
     nd.leaf = 1;
     for (int k = 0; k < 8; ++k) nd.child[k] = -1;
-    nd.rest_begin = 0;
+    nd.rest_begin = nd.begin;
     nd.wsum = 0;
     nd.child_leaf = 0;
     nd._pad = 0;
-    nodes[0] = nd;
-    const bool subdivides = size / 2 > .00000001 && n_points > 10;
-    *owner_of_root_flag = subdivides ? 1 : 0;
-    ctr->n_nodes = 1;
-    ctr->n_next = subdivides ? 1 : 0;
-    ctr->overflow = 0;
-    if (subdivides) active_list[0] = 0;
+    nodes[t] = nd;
+    const bool sub = size / 2 > .00000001 && (nd.end - nd.begin) > 10;
+    subdivides[t] = sub ? 1 : 0;
+    if (sub) active_list[atomicAdd(&ctr->n_next, 1)] = t;
 }
 
-__global__ __launch_bounds__(256) void k_fill_owner(int32_t *owner, int n, const int32_t *root_subdivides)
+// Every point starts out owned by its tree's root, if that root subdivides.
+__global__ __launch_bounds__(256) void k_fill_owner(int32_t *owner, int n, const int32_t *begins, int n_trees, const uint8_t *subdivides)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i < n) owner[i] = *root_subdivides ? 0 : -1;
+    if (i >= n) return;
+    int lo = 0, hi = n_trees - 1;          // the last tree whose range begins at or before i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (begins[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    owner[i] = subdivides[lo] ? lo : -1;
 }
 
 // Before a level: no run has begun yet in the nodes that subdivide on it; nobody is on the next level's list.

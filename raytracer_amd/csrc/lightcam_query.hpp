@@ -70,7 +70,7 @@ DEV double lc_query(const DevLightCam *table, int cam_index, d3 pos, bool active
         ++sp_;                                                          \
     } while (0)
 #define LC_CAP (COOP ? 192 + LC_LDS_STACK : 192)
-    if (active && cam.n_nodes > 0) LC_PUSH(0);
+    if (active && cam.n_nodes > 0) LC_PUSH(cam.root);
     int pend_b = 0, pend_e = 0;
     while (true) {
         bool pending = false;

@@ -347,7 +347,10 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
             if (P.lc_mask) P.lc_mask[pixel] = 1;
             if (P.S.lc_table && closest >= 0) {
                 const int rank = P.S.prim_lc_rank[closest];
-                if (rank >= 0) defer_cam = rank * P.S.n_lights + li;
+                if (rank >= 0) {
+                    defer_cam = rank * P.S.n_lights + li;
+                    P.S.lc_needed[defer_cam] = 1u;       // cameras are set up when a frame first asks for them (Camera.h:417-440)
+                }
             }
         }
         lit = !occluded;
@@ -366,7 +369,7 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
     if (MODE != SHADOW_BVH && P.S.lc_table) {
         bool ok;
         const bool want = defer_cam >= 0;
-        const uint32_t slot = wave_reserve(want, &Q.counts[CNT_DEFER(Q.generation)], Q.hit_shard_cap, &Q.counts[CNT_OVERFLOW + 1], &ok);
+        const uint32_t slot = wave_reserve(want, &Q.counts[CNT_DEFER(Q.generation)], Q.defer_shard_cap, &Q.counts[CNT_OVERFLOW + 1], &ok);
         if (ok) {
             HitRec *dr = &Q.deferred[slot];
             *dr = *hr;
@@ -374,19 +377,10 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
             dr->light = li;
             dr->cam = defer_cam;
             if (hit_flat) dr->mat = P.S.prim_material[hit_prim];
-        } else if (want) {   // queue full: evaluate here
-            const double kfac = lc_calc_intensity(P.S.lc_table, defer_cam, Pt);
-            if (kfac > .01) {
-                lit = true;
-                const rt_light lgt = load_light(P.S, li, true);
-                const double *nsrc = hit_flat ? &P.S.prim_n23[(size_t)hit_prim * 6] : hr->n;
-                const int hit_mat = hit_flat ? P.S.prim_material[hit_prim] : hr->mat;
-                local = phong_terms(load_material(P.S, hit_mat, true), ld3(nsrc), ld3(nsrc + 3), ld3(hr->v), &lgt,
-                                    unit3(sub3(lpos, Pt)), kfac);
-            }
+        } else if (want) {
+            Q.counts[CNT_OVERFLOW] = 1u;      // the queue holds every (hit, light) pair of its generation: not expected; reported
         }
     }
-    STAMP(5);
     accum_add_runs(P.accum, active, lit, pixel, weight, local);
     STAMP(8);
 
@@ -626,7 +620,10 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_FUSED) void k_fused(FrameParams P
                             if (P.lc_mask) P.lc_mask[pixel] = 1;
                             if (P.S.lc_table && closest >= 0) {
                                 const int rank = P.S.prim_lc_rank[closest];
-                                if (rank >= 0) defer_cam = rank * nl + li;
+                                if (rank >= 0) {
+                                    defer_cam = rank * nl + li;
+                                    P.S.lc_needed[defer_cam] = 1u;
+                                }
                             }
                         }
                         lit = !occluded;
@@ -645,7 +642,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_FUSED) void k_fused(FrameParams P
                         // the light camera decides (Camera.h:406-451): postponed to k_lightcam, which runs such queries in full waves
                         bool ok;
                         const bool want = defer_cam >= 0;
-                        const uint32_t slot = wave_reserve(want, &Q.counts[CNT_DEFER(0)], Q.hit_shard_cap, &Q.counts[CNT_OVERFLOW + 1], &ok);
+                        const uint32_t slot = wave_reserve(want, &Q.counts[CNT_DEFER(0)], Q.defer_shard_cap, &Q.counts[CNT_OVERFLOW + 1], &ok);
                         if (ok) {
                             HitRec *dr = &Q.deferred[slot];
                             const rec_v2d q[4] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, vv.x), rec_pack(vv.y, vv.z),
@@ -654,15 +651,8 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_FUSED) void k_fused(FrameParams P
                             const rec_v2d r[4] = {rec_pack_words((uint32_t)li, (uint32_t)defer_cam, (uint32_t)mat, 0u), rec_pack(n2.x, n2.y),
                                                   rec_pack(n2.z, n3.x), rec_pack(n3.y, n3.z)};
                             rec_store(&dr->light, r);
-                        } else if (want) {   // queue full: evaluate here
-                            const double kfac = lc_calc_intensity(P.S.lc_table, defer_cam, Pt);
-                            if (kfac > .01) {
-                                lit = true;
-                                const rt_light lgt = load_light(P.S, li, true);
-                                d3 na = n2, nb = n3;
-                                if (flat) { na = ld3(&P.S.prim_n23[(size_t)prim * 6]); nb = ld3(&P.S.prim_n23[(size_t)prim * 6 + 3]); }
-                                local = phong_terms(load_material(P.S, mat, true), na, nb, vv, &lgt, unit3(sub3(lpos, Pt)), kfac);
-                            }
+                        } else if (want) {
+                            Q.counts[CNT_OVERFLOW] = 1u;      // queue full: the frame is incomplete and is reported as such
                         }
                     }
                     if (lit) sum = add3(sum, mk3(wloc * local.x, wloc * local.y, wloc * local.z));

@@ -104,10 +104,16 @@ struct rt_ctx {
     // host copies needed to set up the light cameras
     std::vector<rt_light> h_lights;
     std::vector<std::array<double, 4>> h_lc_spheres;   // centre + radius of every transparent sphere, by rank
-    std::vector<void *> lc_allocs;
-    void *lc_ws = nullptr; size_t lc_ws_bytes = 0;     // workspace of the device-side tree builder (grow-only)
-    bool lc_built = false;
-    uint32_t lc_built_flags = 0;
+    std::vector<void *> lc_allocs;                     // node and point arrays of the cameras that exist
+    void *lc_ws = nullptr; size_t lc_ws_bytes = 0;     // work space of the device-side tree builder (grow-only)
+    void *lc_photon_ws = nullptr; size_t lc_photon_ws_bytes = 0;     // ... of the photon passes
+    lightcam::Point *lc_packed = nullptr; size_t lc_packed_bytes = 0, lc_packed_points = 0;   // ... their packed impacts
+    DevLightCam *lc_table = nullptr;                   // one entry per (transparent sphere, light) pair
+    uint32_t *lc_needed = nullptr;                     // per pair: raised by the shading passes
+    std::vector<uint8_t> lc_have;                      // per pair: the camera exists
+    std::vector<uint32_t> h_needed;
+    size_t lc_n_built = 0;
+    uint32_t lc_flags = 0;                             // the normal-interpolation mode the cameras were set up for
     unsigned long long lc_rays = 0;
     int32_t lightcam_samples = 150;
     // frame resources (grow-only)
@@ -144,8 +150,12 @@ static void free_lightcams(rt_ctx *ctx)
 {
     for (void *p : ctx->lc_allocs) (void)hipFree(p);
     ctx->lc_allocs.clear();
-    ctx->lc_built = false;
+    (void)hipFree(ctx->lc_table); ctx->lc_table = nullptr;
+    (void)hipFree(ctx->lc_needed); ctx->lc_needed = nullptr;
+    ctx->lc_have.clear();
+    ctx->lc_n_built = 0;
     ctx->S.lc_table = nullptr;
+    ctx->S.lc_needed = nullptr;
     ctx->lc_rays = 0;
 }
 
@@ -251,6 +261,8 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     (void)hipFree(ctx->counts);
     (void)hipFree(ctx->totals);
     (void)hipFree(ctx->lc_ws);
+    (void)hipFree(ctx->lc_photon_ws);
+    (void)hipFree(ctx->lc_packed);
     for (void *p : ctx->stage) (void)hipFree(p);
     for (auto &pr : ctx->ev_closest) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : ctx->ev_shadow) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -451,6 +463,7 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
         ctx->h_lights.assign(s->lights, s->lights + s->n_lights);
     }
     D.lc_table = nullptr;
+    D.lc_needed = nullptr;
     D.n_nodes = s->n_nodes;
     D.n_lights = s->n_lights;
     D.bg[0] = s->background[0]; D.bg[1] = s->background[1]; D.bg[2] = s->background[2];
@@ -536,18 +549,39 @@ static std::pair<hipEvent_t, hipEvent_t> *next_event_pair(std::vector<std::pair<
     return &v[used++];
 }
 
-// ------------------------------------------------------------------ light cameras: point octree on the device
-// Builds the point octree of one light camera from its packed impacts (lightcam_device.hpp) on stream `st`.
-// `d_pts` (n_pts points, ray order) is consumed; on success *nodes_out / *points_out are exact-size allocations the
-// caller owns.  Returns RT_ERR_CAPACITY when the node array of the workspace is too small (the caller then takes the
-// host builder).
-static int build_tree_on_device(rt_ctx *ctx, hipStream_t st, const lightcam::Point *d_pts, int n_pts, const unsigned long long *d_max_bits,
-                                void **nodes_out, int32_t *n_nodes_out, void **points_out, int *levels_out)
+// ------------------------------------------------------------------ light cameras
+// A light camera belongs to a (transparent sphere, light) pair and is set up the first time a frame's shading points
+// ask for it (Camera.h:417-440): the shading passes raise the pair's word in DevScene::lc_needed, and before a batch's
+// density queries run, the cameras that are asked for and do not exist yet are built -- all of them together:
+//   photon pass per pair (k_photons), impacts packed in ray order into one shared array (prefix sum of the per-ray
+//   counts), then ONE level-synchronous build of all their point octrees (lightcam_device.hpp) into one shared node
+//   array, a root per camera.
+// The host builder (lightcam_build.cpp, one thread per tree) is kept behind the "lightcam_host" option.
+#define LC_MAX_PAIRS (1 << 20)
+
+template <typename T>
+static int ws_ensure(T **ptr, size_t *have, size_t want)
+{
+    if (*ptr && *have >= want) return RT_OK;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr; *have = 0;
+    HIP_TRY(hipMalloc((void **)ptr, want ? want : 1));
+    *have = want;
+    return RT_OK;
+}
+
+// Builds the point octrees of `n_trees` cameras whose impacts lie in d_pts (tree t: [h_begins[t], h_begins[t+1])) on
+// stream `st`.  d_pts is used as work space.  On success *nodes_out / *points_out are exact-size allocations the caller
+// owns: tree t's root is node t, node ranges index *points_out.
+static int build_trees_on_device(rt_ctx *ctx, hipStream_t st, lightcam::Point *d_pts, const std::vector<int32_t> &h_begins,
+                                 const unsigned long long *d_max_bits, void **nodes_out, int32_t *n_nodes_out, void **points_out, int *levels_out)
 {
     *nodes_out = *points_out = nullptr;
     *n_nodes_out = 0;
+    const int n_trees = (int)h_begins.size() - 1;
+    const int n_pts = h_begins.back();
     const size_t n = (size_t)(n_pts > 0 ? n_pts : 1);
-    const size_t cap = 2 * n + 1024;                      // nodes; a tree has about 0.4 nodes per point
+    const size_t cap = 2 * n + 1024 + (size_t)n_trees;     // nodes; a tree has about 0.4 nodes per point
     int key_bits = 5;
     while (((size_t)1 << (key_bits - 4)) < n + 1 && key_bits < 60) ++key_bits;
     size_t sort_bytes = 0;
@@ -556,21 +590,16 @@ static int build_tree_on_device(rt_ctx *ctx, hipStream_t st, const lightcam::Poi
         hipcub::DoubleBuffer<uint32_t> dv(nullptr, nullptr);
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, dk, dv, (int)n, 0, key_bits, st));
     }
-    // workspace layout
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_pts = take(n * sizeof(lightcam::Point)), o_key0 = take(n * 8), o_key1 = take(n * 8), o_idx0 = take(n * 4),
                  o_idx1 = take(n * 4), o_own0 = take(n * 4), o_own1 = take(n * 4), o_nodes = take(cap * sizeof(lightcam::Node)),
                  o_runs = take(cap * 9 * 4), o_sub = take(cap), o_act0 = take(cap * 4), o_act1 = take(cap * 4),
-                 o_ctr = take(sizeof(lcdev::LevelCounters)), o_flag = take(4), o_sort = take(sort_bytes);
-    if (ctx->lc_ws_bytes < off) {
-        if (ctx->lc_ws) HIP_TRY(hipFree(ctx->lc_ws));
-        ctx->lc_ws = nullptr; ctx->lc_ws_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->lc_ws, off));
-        ctx->lc_ws_bytes = off;
-    }
+                 o_ctr = take(sizeof(lcdev::LevelCounters)), o_begins = take((size_t)(n_trees + 1) * 4), o_sort = take(sort_bytes);
+    int rc = ws_ensure(&ctx->lc_ws, &ctx->lc_ws_bytes, off);
+    if (rc != RT_OK) return rc;
     unsigned char *ws = static_cast<unsigned char *>(ctx->lc_ws);
-    lightcam::Point *pts[2] = {const_cast<lightcam::Point *>(d_pts), reinterpret_cast<lightcam::Point *>(ws + o_pts)};
+    lightcam::Point *pts[2] = {d_pts, reinterpret_cast<lightcam::Point *>(ws + o_pts)};
     unsigned long long *key[2] = {reinterpret_cast<unsigned long long *>(ws + o_key0), reinterpret_cast<unsigned long long *>(ws + o_key1)};
     uint32_t *idx[2] = {reinterpret_cast<uint32_t *>(ws + o_idx0), reinterpret_cast<uint32_t *>(ws + o_idx1)};
     int32_t *owner[2] = {reinterpret_cast<int32_t *>(ws + o_own0), reinterpret_cast<int32_t *>(ws + o_own1)};
@@ -579,19 +608,22 @@ static int build_tree_on_device(rt_ctx *ctx, hipStream_t st, const lightcam::Poi
     uint8_t *subdiv = ws + o_sub;
     int32_t *active[2] = {reinterpret_cast<int32_t *>(ws + o_act0), reinterpret_cast<int32_t *>(ws + o_act1)};
     lcdev::LevelCounters *ctr = reinterpret_cast<lcdev::LevelCounters *>(ws + o_ctr);
-    int32_t *flag = reinterpret_cast<int32_t *>(ws + o_flag);
+    int32_t *d_begins = reinterpret_cast<int32_t *>(ws + o_begins);
     void *sort_ws = ws + o_sort;
 
     const unsigned pb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(lcdev::k_root, dim3(1), dim3(64), 0, st, nodes, d_max_bits, n_pts, flag, ctr, active[0]);
-    hipLaunchKernelGGL(lcdev::k_fill_owner, dim3(pb), dim3(256), 0, st, owner[0], n_pts, flag);
     lcdev::LevelCounters h{};
+    h.n_nodes = n_trees;
+    HIP_TRY(hipMemcpyAsync(ctr, &h, sizeof h, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_begins, h_begins.data(), (size_t)(n_trees + 1) * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(lcdev::k_roots, dim3((unsigned)((n_trees + 63) / 64)), dim3(64), 0, st, nodes, d_max_bits, d_begins, n_trees, subdiv, ctr, active[0]);
+    if (n_pts > 0) hipLaunchKernelGGL(lcdev::k_fill_owner, dim3(pb), dim3(256), 0, st, owner[0], n_pts, d_begins, n_trees, subdiv);
     HIP_TRY(hipMemcpyAsync(&h, ctr, sizeof h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     int cur = 0, levels = 0;        // pts[cur], owner[cur], active[cur] are the current level's
     while (h.n_next > 0) {
         const int n_active = h.n_next;
-        if ((size_t)h.n_nodes + 8 * (size_t)n_active > cap) return fail(RT_ERR_CAPACITY, "light-camera tree: node workspace too small");
+        if ((size_t)h.n_nodes + 8 * (size_t)n_active > cap) return fail(RT_ERR_CAPACITY, "light-camera trees: node workspace too small");
         hipLaunchKernelGGL(lcdev::k_clear_runs, dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, active[cur], n_active, runs, ctr);
         hipLaunchKernelGGL(lcdev::k_classify, dim3(pb), dim3(256), 0, st, pts[cur], owner[cur], nodes, n_pts, key[0], idx[0]);
         hipcub::DoubleBuffer<unsigned long long> dk(key[0], key[1]);
@@ -606,21 +638,21 @@ static int build_tree_on_device(rt_ctx *ctx, hipStream_t st, const lightcam::Poi
         hipLaunchKernelGGL(lcdev::k_next_owner, dim3(pb), dim3(256), 0, st, key_sorted, owner[cur ^ 1], nodes, subdiv, n_pts);
         HIP_TRY(hipMemcpyAsync(&h, ctr, sizeof h, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (h.overflow) return fail(RT_ERR_CAPACITY, "light-camera tree: node workspace too small");
+        if (h.overflow) return fail(RT_ERR_CAPACITY, "light-camera trees: node workspace too small");
         cur ^= 1;
-        if (++levels > 80) return fail(RT_ERR_DEVICE, "light-camera tree: the build does not terminate");
+        if (++levels > 80) return fail(RT_ERR_DEVICE, "light-camera trees: the build does not terminate");
     }
-    hipLaunchKernelGGL(lcdev::k_finish_nodes, dim3((unsigned)(h.n_nodes < 1024 ? (h.n_nodes + 3) / 4 : 1024)), dim3(256), 0, st, nodes, h.n_nodes,
+    hipLaunchKernelGGL(lcdev::k_finish_nodes, dim3((unsigned)(h.n_nodes < 4096 ? (h.n_nodes + 3) / 4 : 1024)), dim3(256), 0, st, nodes, h.n_nodes,
                        pts[cur]);
     HIP_TRY(hipGetLastError());
     void *dn = nullptr, *dp = nullptr;
     HIP_TRY(hipMalloc(&dn, sizeof(lightcam::Node) * (size_t)h.n_nodes));
-    if (hipMalloc(&dp, sizeof(lightcam::Point) * n) != hipSuccess) { (void)hipFree(dn); return fail(RT_ERR_DEVICE, "hipMalloc failed for a light-camera tree"); }
+    if (hipMalloc(&dp, sizeof(lightcam::Point) * n) != hipSuccess) { (void)hipFree(dn); return fail(RT_ERR_DEVICE, "hipMalloc failed for light-camera trees"); }
     if (hipMemcpyAsync(dn, nodes, sizeof(lightcam::Node) * (size_t)h.n_nodes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(dp, pts[cur], sizeof(lightcam::Point) * (size_t)n_pts, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        (n_pts > 0 && hipMemcpyAsync(dp, pts[cur], sizeof(lightcam::Point) * (size_t)n_pts, hipMemcpyDeviceToDevice, st) != hipSuccess) ||
         hipStreamSynchronize(st) != hipSuccess) {
         (void)hipFree(dn); (void)hipFree(dp);
-        return fail(RT_ERR_DEVICE, "light-camera tree: copy out of the workspace failed");
+        return fail(RT_ERR_DEVICE, "light-camera trees: copy out of the workspace failed");
     }
     *nodes_out = dn;
     *points_out = dp;
@@ -629,224 +661,201 @@ static int build_tree_on_device(rt_ctx *ctx, hipStream_t st, const lightcam::Poi
     return RT_OK;
 }
 
-// Builds the light camera of every (transparent sphere, light) pair: photon pass on the device,
-// point octree on the host (lightcam_build.cpp), flattened tree back to the device.  The reference
-// creates a camera the first time a shading point needs it (Camera.h:417-440); a camera depends
-// only on its pair, so building all of them ahead changes no pixel.
-// All cameras are built ahead, so their number is bounded: by LC_MAX_PAIRS, and by memory -- a light
-// ray leaves about three weighted points, and a point costs about 64 bytes with its share of the tree;
-// the cameras may take a quarter of the free device memory.  Beyond either bound the call fails with
-// RT_ERR_CAPACITY (a frame without the term would differ from the reference's); RT_FLAG_NO_LIGHTCAM
-// renders such a scene without it on request.
-#define LC_MAX_PAIRS 4096
-static int build_lightcams(rt_ctx *ctx, uint32_t flags, bool cull)
+// The table of cameras (one entry per pair, all "not built") and the words the shading passes raise.
+static int ensure_lightcam_table(rt_ctx *ctx, uint32_t lc_flags)
 {
-    free_lightcams(ctx);
     const size_t n_pairs = ctx->h_lc_spheres.size() * ctx->h_lights.size();
-    if (n_pairs == 0) return RT_OK;
+    if (ctx->lc_table && ctx->lc_flags == lc_flags) return RT_OK;
+    free_lightcams(ctx);
     if (n_pairs > LC_MAX_PAIRS)
-        return fail(RT_ERR_CAPACITY, "rt_render: " + std::to_string(n_pairs) + " (transparent sphere, light) pairs, more than the " +
-                                         std::to_string(LC_MAX_PAIRS) + " light cameras this build sets up; RT_FLAG_NO_LIGHTCAM renders without the term");
+        return fail(RT_ERR_CAPACITY, "rt_render: " + std::to_string(n_pairs) + " (transparent sphere, light) pairs, more than the table of " +
+                                         std::to_string(LC_MAX_PAIRS) + " light cameras; RT_FLAG_NO_LIGHTCAM renders without the term");
+    HIP_TRY(hipMalloc((void **)&ctx->lc_table, sizeof(DevLightCam) * n_pairs));
+    if (hipMalloc((void **)&ctx->lc_needed, sizeof(uint32_t) * n_pairs) != hipSuccess) {
+        (void)hipFree(ctx->lc_table); ctx->lc_table = nullptr;
+        return fail(RT_ERR_DEVICE, "hipMalloc failed for the light-camera table");
+    }
+    HIP_TRY(hipMemset(ctx->lc_table, 0, sizeof(DevLightCam) * n_pairs));
+    HIP_TRY(hipMemset(ctx->lc_needed, 0, sizeof(uint32_t) * n_pairs));
+    ctx->lc_have.assign(n_pairs, 0);
+    ctx->lc_n_built = 0;
+    ctx->lc_flags = lc_flags;
+    ctx->h_needed.resize(n_pairs);
+    return RT_OK;
+}
+
+// Sets up the cameras of `pairs` (indices rank * n_lights + light), all together, and enters them in the table.
+static int build_lightcams(rt_ctx *ctx, const std::vector<int32_t> &pairs, uint32_t flags, bool cull)
+{
+    if (pairs.empty()) return RT_OK;
     const int N = ctx->lightcam_samples;
     if (N < 1 || N > 4096) return fail(RT_ERR_INVALID, "light camera sample count (Z) must be in 1..4096");
-    const size_t n_rays = (size_t)N * N;
+    const size_t n_rays = (size_t)N * N, n_build = pairs.size(), n_lights = ctx->h_lights.size();
+    const auto t_begin = std::chrono::steady_clock::now();
     {
+        // a light ray leaves about three weighted points, and a point costs about 64 bytes with its share of the tree (twice
+        // that while it is being built): the cameras of one call may take half of the free device memory
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if ((double)n_pairs * (double)n_rays * 3.0 * 64.0 > 0.25 * (double)free_b)
-            return fail(RT_ERR_CAPACITY, "rt_render: the light cameras of this scene would need more than a quarter of the free device "
+        if ((double)n_build * (double)n_rays * 3.0 * 128.0 > 0.5 * (double)free_b)
+            return fail(RT_ERR_CAPACITY, "rt_render: the light cameras this frame asks for would need more than half of the free device "
                                          "memory; RT_FLAG_NO_LIGHTCAM renders without the term");
     }
-    lightcam::Point *d_slots = nullptr;
-    int32_t *d_counts = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_slots, n_rays * LC_MAX_IMPACTS * sizeof(lightcam::Point)));
-    if (hipMalloc((void **)&d_counts, n_rays * sizeof(int32_t)) != hipSuccess) {
-        (void)hipFree(d_slots);
-        return fail(RT_ERR_DEVICE, "hipMalloc failed for the light-camera counts");
-    }
-    uint32_t *d_offsets = nullptr;
-    if (hipMalloc((void **)&d_offsets, n_rays * sizeof(uint32_t)) != hipSuccess) {
-        (void)hipFree(d_slots);
-        (void)hipFree(d_counts);
-        return fail(RT_ERR_DEVICE, "hipMalloc failed for the light-camera offsets");
-    }
-    // device path: 16 bytes of counters (castLightRay calls, largest |impact|), the impact counts as words, scan workspace
-    unsigned char *d_meta_raw = nullptr;
+    hipStream_t st = ctx->stream;
+    // work space of the photon passes: 21 impact slots per ray, per-ray counts, offsets, counters (2 words per camera:
+    // largest |impact| as bits, castLightRay calls), prefix-sum scratch
     size_t scan_bytes = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_rays, ctx->stream);
-    if (hipMalloc((void **)&d_meta_raw, 256 + n_rays * sizeof(uint32_t) + 256 + scan_bytes) != hipSuccess) {
-        (void)hipFree(d_slots); (void)hipFree(d_counts); (void)hipFree(d_offsets);
-        return fail(RT_ERR_DEVICE, "hipMalloc failed for the light-camera workspace");
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_rays, st);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_slots = take(n_rays * LC_MAX_IMPACTS * sizeof(lightcam::Point)), o_counts = take(n_rays * 4), o_cnt32 = take(n_rays * 4),
+                 o_offsets = take(n_rays * 4), o_meta = take(n_build * 16), o_scan = take(scan_bytes);
+    int rc = ws_ensure(&ctx->lc_photon_ws, &ctx->lc_photon_ws_bytes, off);
+    if (rc != RT_OK) return rc;
+    unsigned char *pw = static_cast<unsigned char *>(ctx->lc_photon_ws);
+    lightcam::Point *d_slots = reinterpret_cast<lightcam::Point *>(pw + o_slots);
+    int32_t *d_counts = reinterpret_cast<int32_t *>(pw + o_counts);
+    uint32_t *d_cnt32 = reinterpret_cast<uint32_t *>(pw + o_cnt32), *d_offsets = reinterpret_cast<uint32_t *>(pw + o_offsets);
+    unsigned long long *d_meta = reinterpret_cast<unsigned long long *>(pw + o_meta);
+    void *d_scan = pw + o_scan;
+    HIP_TRY(hipMemsetAsync(d_meta, 0, n_build * 16, st));
+
+    // the impacts of all cameras of this call, packed one camera after the other (grows when the estimate was short)
+    size_t packed_cap = ctx->lc_packed_points;
+    if (packed_cap < n_build * n_rays * 3) {
+        rc = ws_ensure(&ctx->lc_packed, &ctx->lc_packed_bytes, n_build * n_rays * 3 * sizeof(lightcam::Point));
+        if (rc != RT_OK) return rc;
+        packed_cap = ctx->lc_packed_points = ctx->lc_packed_bytes / sizeof(lightcam::Point);
     }
-    uint32_t *d_meta = reinterpret_cast<uint32_t *>(d_meta_raw);          // words 0..3: the two counters; from word 64: the counts
-    void *d_scan_ws = d_meta_raw + 256 + ((n_rays * sizeof(uint32_t) + 255) & ~(size_t)255);
-    std::vector<uint32_t> h_offsets(n_rays);
-    std::vector<int32_t> h_counts(n_rays);
-    std::vector<DevLightCam> table(n_pairs);
-    struct PairWork {
-        std::vector<lightcam::Point> pts;
-        lightcam::Tree tree;
-        double max_dist = 0, spw = 0, light_pos[3] = {0, 0, 0}, sphere_pos[3] = {0, 0, 0};
-    };
-    // Eight pairs at a time: their photon passes one after the other on the device, their point octrees
-    // side by side on host threads (the trees are independent), then the uploads.
-    constexpr size_t kGroup = 8;
-    std::vector<PairWork> work(kGroup);
-    int rc = RT_OK;
-    double build_ms = 0;
-    const size_t n_lights = ctx->h_lights.size();
-    std::vector<std::thread> pool;
-    for (size_t first = 0; first < n_pairs && rc == RT_OK; first += kGroup) {
-        const size_t last = first + kGroup < n_pairs ? first + kGroup : n_pairs;
-        for (size_t pair = first; pair < last && rc == RT_OK; ++pair) {
-            const size_t r = pair / n_lights, li = pair % n_lights;
-            const auto &sp = ctx->h_lc_spheres[r];
-            const rt_light &lt = ctx->h_lights[li];
-            lightcam::Frame fr;
-            const double spos[3] = {sp[0], sp[1], sp[2]};
-            lightcam::setup_frame(lt.pos, spos, sp[3], fr);
-            PhotonParams Q{};
-            Q.S = ctx->S;
-            for (int k = 0; k < 3; ++k) { Q.u[k] = fr.u[k]; Q.v[k] = fr.v[k]; Q.w[k] = fr.w[k]; Q.e[k] = fr.e[k]; }
-            Q.d = fr.d; Q.l = fr.l; Q.t = fr.t; Q.pix_width = fr.pix_width;
-            Q.N = N;
-            Q.flags = flags;
-            Q.cull = cull ? 1 : 0;
-            Q.slots = d_slots;
-            Q.counts = d_counts;
-            hipLaunchKernelGGL(k_photons, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, ctx->stream, Q);
-            if (!ctx->dbg.lightcam_host) {
-                // everything stays on the device: offsets by a prefix sum, the impacts packed in ray order, the tree built
-                // level by level (lightcam_device.hpp); the host reads back a few words per level
-                hipStream_t st = ctx->stream;
-                const unsigned rb = (unsigned)((n_rays + 255) / 256);
-                uint32_t *d_cnt32 = d_meta + 64;
-                hipLaunchKernelGGL(lcdev::k_impact_counts, dim3(rb), dim3(256), 0, st, d_counts, (int)n_rays, d_cnt32);
-                size_t sb = scan_bytes;
-                bool ok = hipcub::DeviceScan::ExclusiveSum(d_scan_ws, sb, d_cnt32, d_offsets, (int)n_rays, st) == hipSuccess;
-                uint32_t last_off = 0, last_cnt = 0;
-                ok = ok && hipMemcpyAsync(&last_off, d_offsets + (n_rays - 1), 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                     hipMemcpyAsync(&last_cnt, d_cnt32 + (n_rays - 1), 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                     hipMemsetAsync(d_meta, 0, 16, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-                if (!ok) { rc = fail(RT_ERR_DEVICE, "light-camera photon pass failed"); break; }
-                const size_t n_pts = (size_t)last_off + last_cnt;
-                if (n_pts >= ((size_t)1 << 31)) { rc = fail(RT_ERR_CAPACITY, "light camera with more than 2^31 impacts"); break; }
-                lightcam::Point *d_packed = nullptr;
-                if (hipMalloc((void **)&d_packed, (n_pts ? n_pts : 1) * sizeof(lightcam::Point)) != hipSuccess) {
-                    rc = fail(RT_ERR_DEVICE, "hipMalloc failed for a light camera's impacts");
-                    break;
-                }
-                hipLaunchKernelGGL(lcdev::k_pack_photons, dim3(rb), dim3(256), 0, st, d_slots, d_counts, d_offsets, (int)n_rays, LC_MAX_IMPACTS, d_packed,
-                                   reinterpret_cast<unsigned long long *>(d_meta), reinterpret_cast<unsigned long long *>(d_meta) + 1);
-                void *dn = nullptr, *dp = nullptr;
-                int32_t n_nodes = 0;
-                int levels = 0;
-                int trc = build_tree_on_device(ctx, st, d_packed, (int)n_pts, reinterpret_cast<unsigned long long *>(d_meta) + 1, &dn, &n_nodes, &dp, &levels);
-                unsigned long long calls = 0;
-                if (trc == RT_OK && hipMemcpy(&calls, d_meta, 8, hipMemcpyDeviceToHost) != hipSuccess) trc = fail(RT_ERR_DEVICE, "light-camera readback failed");
-                (void)hipFree(d_packed);
-                if (trc != RT_OK) { if (dn) (void)hipFree(dn); if (dp) (void)hipFree(dp); rc = trc; break; }
-                ctx->lc_rays += calls;
-                ctx->lc_allocs.push_back(dn);
-                ctx->lc_allocs.push_back(dp);
-                DevLightCam cam{};
-                cam.nodes = static_cast<const lightcam::Node *>(dn);
-                cam.points = static_cast<const lightcam::Point *>(dp);
-                cam.n_nodes = n_nodes;
-                cam.n_points = (int32_t)n_pts;
-                cam.spw = fr.pix_width / N;
-                for (int c = 0; c < 3; ++c) { cam.light_pos[c] = lt.pos[c]; cam.sphere_pos[c] = spos[c]; }
-                table[pair] = cam;
-                if (ctx->dbg.verbose) fprintf(stderr, "[rt] light camera %zu: %zu impacts, %d nodes, %d levels (built on the device)\n", pair, n_pts, n_nodes, levels);
-                continue;
-            }
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
-                hipMemcpy(h_counts.data(), d_counts, n_rays * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
-                rc = fail(RT_ERR_DEVICE, "light-camera photon pass failed");
-                break;
-            }
-            // most rays leave two or three impacts in their 21 slots: pack them on the device (ray order
-            // kept, it is the order the reference inserts them in) and fetch only those
-            size_t n_pts = 0;
-            for (size_t i = 0; i < n_rays; ++i) {
-                h_offsets[i] = (uint32_t)n_pts;
-                n_pts += (size_t)(h_counts[i] & 0xff);
-                ctx->lc_rays += (unsigned long long)(h_counts[i] >> 8);
-            }
-            std::vector<lightcam::Point> pts(n_pts);
-            if (n_pts) {
-                lightcam::Point *d_packed = nullptr;
-                bool ok = hipMalloc((void **)&d_packed, n_pts * sizeof(lightcam::Point)) == hipSuccess &&
-                          hipMemcpy(d_offsets, h_offsets.data(), n_rays * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
-                if (ok) {
-                    hipLaunchKernelGGL(k_pack_photons, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, ctx->stream, d_slots,
-                                       d_counts, d_offsets, (int)n_rays, LC_MAX_IMPACTS, d_packed);
-                    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess &&
-                         hipMemcpy(pts.data(), d_packed, n_pts * sizeof(lightcam::Point), hipMemcpyDeviceToHost) == hipSuccess;
-                }
-                if (d_packed) (void)hipFree(d_packed);
-                if (!ok) { rc = fail(RT_ERR_DEVICE, "light-camera photon pass: packing the impacts failed"); break; }
-            }
-            double max_dist = 0;
-            for (const lightcam::Point &p : pts) {
-                const double dz = lightcam::length3(p.x, p.y, p.z);
-                if (dz > max_dist) max_dist = dz;     // std::max(distToOrigin, maxDistFromZero)
-            }
-            PairWork &pw = work[pair - first];
-            pw.pts.swap(pts);
-            pw.max_dist = max_dist;
-            pw.spw = fr.pix_width / N;
-            for (int k = 0; k < 3; ++k) { pw.light_pos[k] = lt.pos[k]; pw.sphere_pos[k] = spos[k]; }
-            // the tree of this pair is built on a host thread while the device runs the next pair's photon pass
-            pool.emplace_back([&pw]() { lightcam::build(pw.pts, pw.max_dist, pw.tree); });
+    std::vector<int32_t> begins(n_build + 1, 0);
+    std::vector<DevLightCam> cams(n_build);
+    const unsigned rb = (unsigned)((n_rays + 255) / 256);
+    for (size_t b = 0; b < n_build; ++b) {
+        const size_t pair = (size_t)pairs[b], r = pair / n_lights, li = pair % n_lights;
+        const auto &sp = ctx->h_lc_spheres[r];
+        const rt_light &lt = ctx->h_lights[li];
+        lightcam::Frame fr;
+        const double spos[3] = {sp[0], sp[1], sp[2]};
+        lightcam::setup_frame(lt.pos, spos, sp[3], fr);
+        PhotonParams Q{};
+        Q.S = ctx->S;
+        for (int k = 0; k < 3; ++k) { Q.u[k] = fr.u[k]; Q.v[k] = fr.v[k]; Q.w[k] = fr.w[k]; Q.e[k] = fr.e[k]; }
+        Q.d = fr.d; Q.l = fr.l; Q.t = fr.t; Q.pix_width = fr.pix_width;
+        Q.N = N;
+        Q.flags = flags;
+        Q.cull = cull ? 1 : 0;
+        Q.slots = d_slots;
+        Q.counts = d_counts;
+        hipLaunchKernelGGL(k_photons, dim3(rb), dim3(256), 0, st, Q);
+        hipLaunchKernelGGL(lcdev::k_impact_counts, dim3(rb), dim3(256), 0, st, d_counts, (int)n_rays, d_cnt32);
+        size_t sb = scan_bytes;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, d_cnt32, d_offsets, (int)n_rays, st));
+        uint32_t last_off = 0, last_cnt = 0;
+        HIP_TRY(hipMemcpyAsync(&last_off, d_offsets + (n_rays - 1), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&last_cnt, d_cnt32 + (n_rays - 1), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const size_t n_pts = (size_t)last_off + last_cnt;
+        if ((size_t)begins[b] + n_pts >= ((size_t)1 << 31)) return fail(RT_ERR_CAPACITY, "light cameras of one frame with more than 2^31 impacts");
+        if ((size_t)begins[b] + n_pts > packed_cap) {
+            // the estimate was short: a larger array, the impacts packed so far carried over
+            lightcam::Point *bigger = nullptr;
+            const size_t want = ((size_t)begins[b] + n_pts) * 2;
+            HIP_TRY(hipMalloc((void **)&bigger, want * sizeof(lightcam::Point)));
+            if (begins[b] > 0) HIP_TRY(hipMemcpy(bigger, ctx->lc_packed, (size_t)begins[b] * sizeof(lightcam::Point), hipMemcpyDeviceToDevice));
+            (void)hipFree(ctx->lc_packed);
+            ctx->lc_packed = bigger;
+            ctx->lc_packed_bytes = want * sizeof(lightcam::Point);
+            packed_cap = ctx->lc_packed_points = want;
         }
-        {
-            const auto t0 = std::chrono::steady_clock::now();
-            for (std::thread &t : pool) t.join();
-            pool.clear();
-            build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        }
-        if (rc != RT_OK) break;
-        for (size_t k = 0; ctx->dbg.lightcam_host && k < last - first && rc == RT_OK; ++k) {
-            const lightcam::Tree &tree = work[k].tree;
-            DevLightCam cam{};
-            void *dn = nullptr, *dp = nullptr;
-            if (hipMalloc(&dn, sizeof(lightcam::Node) * (tree.nodes.size() ? tree.nodes.size() : 1)) != hipSuccess ||
-                hipMalloc(&dp, sizeof(lightcam::Point) * (tree.points.size() ? tree.points.size() : 1)) != hipSuccess) {
-                if (dn) (void)hipFree(dn);
-                rc = fail(RT_ERR_DEVICE, "hipMalloc failed for a light-camera tree");
-                break;
-            }
-            ctx->lc_allocs.push_back(dn);
-            ctx->lc_allocs.push_back(dp);
-            if (hipMemcpy(dn, tree.nodes.data(), sizeof(lightcam::Node) * tree.nodes.size(), hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(dp, tree.points.data(), sizeof(lightcam::Point) * tree.points.size(), hipMemcpyHostToDevice) != hipSuccess) {
-                rc = fail(RT_ERR_DEVICE, "upload of a light-camera tree failed");
-                break;
-            }
-            cam.nodes = static_cast<const lightcam::Node *>(dn);
-            cam.points = static_cast<const lightcam::Point *>(dp);
-            cam.n_nodes = (int32_t)tree.nodes.size();
-            cam.n_points = (int32_t)tree.points.size();
-            cam.spw = work[k].spw;
-            for (int c = 0; c < 3; ++c) { cam.light_pos[c] = work[k].light_pos[c]; cam.sphere_pos[c] = work[k].sphere_pos[c]; }
-            table[first + k] = cam;
-        }
+        hipLaunchKernelGGL(lcdev::k_pack_photons, dim3(rb), dim3(256), 0, st, d_slots, d_counts, d_offsets, (int)n_rays, LC_MAX_IMPACTS,
+                           ctx->lc_packed + begins[b], d_meta + 2 * b, d_meta + 2 * b + 1);
+        begins[b + 1] = begins[b] + (int32_t)n_pts;
+        DevLightCam cam{};
+        cam.root = (int32_t)b;
+        cam.n_points = (int32_t)n_pts;
+        cam.spw = fr.pix_width / N;
+        for (int c = 0; c < 3; ++c) { cam.light_pos[c] = lt.pos[c]; cam.sphere_pos[c] = spos[c]; }
+        cams[b] = cam;
     }
-    (void)hipFree(d_slots);
-    (void)hipFree(d_counts);
-    (void)hipFree(d_offsets);
-    (void)hipFree(d_meta_raw);
-    if (ctx->dbg.verbose) fprintf(stderr, "[rt] %zu light-camera trees: %.1f ms waiting for the host threads after the photon passes\n", n_pairs, build_ms);
-    if (rc != RT_OK) { free_lightcams(ctx); return rc; }
-    void *dt = nullptr;
-    HIP_TRY(hipMalloc(&dt, sizeof(DevLightCam) * n_pairs));
-    ctx->lc_allocs.push_back(dt);
-    HIP_TRY(hipMemcpy(dt, table.data(), sizeof(DevLightCam) * n_pairs, hipMemcpyHostToDevice));
-    ctx->S.lc_table = static_cast<const DevLightCam *>(dt);
-    ctx->lc_built = true;
-    ctx->lc_built_flags = flags;
+    HIP_TRY(hipGetLastError());
+    void *dn = nullptr, *dp = nullptr;
+    int32_t n_nodes = 0;
+    int levels = 0;
+    if (!ctx->dbg.lightcam_host) {
+        rc = build_trees_on_device(ctx, st, ctx->lc_packed, begins, d_meta, &dn, &n_nodes, &dp, &levels);
+        if (rc != RT_OK) return rc;
+    } else {
+        // host builder: every tree on a thread of its own, the node lists joined behind the roots (root b = node b)
+        const size_t n_pts = (size_t)begins[n_build];
+        std::vector<lightcam::Point> all(n_pts ? n_pts : 1);
+        HIP_TRY(hipStreamSynchronize(st));
+        if (n_pts) HIP_TRY(hipMemcpy(all.data(), ctx->lc_packed, n_pts * sizeof(lightcam::Point), hipMemcpyDeviceToHost));
+        std::vector<lightcam::Tree> trees(n_build);
+        std::vector<std::thread> pool;
+        for (size_t b = 0; b < n_build; ++b)
+            pool.emplace_back([&, b]() {
+                std::vector<lightcam::Point> pts(all.begin() + begins[b], all.begin() + begins[b + 1]);
+                double max_dist = 0;
+                for (const lightcam::Point &q : pts) { const double dz = lightcam::length3(q.x, q.y, q.z); if (dz > max_dist) max_dist = dz; }
+                lightcam::build(pts, max_dist, trees[b]);
+            });
+        for (std::thread &t : pool) t.join();
+        std::vector<lightcam::Node> nodes(n_build);
+        std::vector<lightcam::Point> points;
+        points.reserve(n_pts);
+        for (size_t b = 0; b < n_build; ++b) {
+            const int32_t shift = (int32_t)nodes.size() - 1, pshift = begins[b];       // node k > 0 of tree b becomes node shift + k
+            for (size_t k = 0; k < trees[b].nodes.size(); ++k) {
+                lightcam::Node nd = trees[b].nodes[k];
+                for (int c = 0; c < 8; ++c) if (nd.child[c] >= 0) nd.child[c] += shift;
+                nd.begin += pshift; nd.end += pshift; nd.rest_begin += pshift;
+                if (k == 0) nodes[b] = nd; else nodes.push_back(nd);
+            }
+            points.insert(points.end(), trees[b].points.begin(), trees[b].points.end());
+        }
+        n_nodes = (int32_t)nodes.size();
+        HIP_TRY(hipMalloc(&dn, sizeof(lightcam::Node) * nodes.size()));
+        if (hipMalloc(&dp, sizeof(lightcam::Point) * (points.size() ? points.size() : 1)) != hipSuccess) { (void)hipFree(dn); return fail(RT_ERR_DEVICE, "hipMalloc failed for light-camera trees"); }
+        HIP_TRY(hipMemcpy(dn, nodes.data(), sizeof(lightcam::Node) * nodes.size(), hipMemcpyHostToDevice));
+        if (!points.empty()) HIP_TRY(hipMemcpy(dp, points.data(), sizeof(lightcam::Point) * points.size(), hipMemcpyHostToDevice));
+    }
+    ctx->lc_allocs.push_back(dn);
+    ctx->lc_allocs.push_back(dp);
+    std::vector<unsigned long long> meta(n_build * 2);
+    HIP_TRY(hipMemcpy(meta.data(), d_meta, n_build * 16, hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < n_build; ++b) {
+        cams[b].nodes = static_cast<const lightcam::Node *>(dn);
+        cams[b].points = static_cast<const lightcam::Point *>(dp);
+        cams[b].n_nodes = n_nodes;
+        ctx->lc_rays += meta[2 * b + 1];
+        HIP_TRY(hipMemcpy(ctx->lc_table + pairs[b], &cams[b], sizeof(DevLightCam), hipMemcpyHostToDevice));
+        ctx->lc_have[(size_t)pairs[b]] = 1;
+        ctx->lc_n_built++;
+    }
+    if (ctx->dbg.verbose)
+        fprintf(stderr, "[rt] %zu light cameras set up in %.2f ms: %d impacts, %d nodes, %d levels (%s builder)\n", n_build,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), begins[n_build], n_nodes, levels,
+                ctx->dbg.lightcam_host ? "host" : "device");
     return RT_OK;
+}
+
+// Before a batch's density queries: the cameras its shading passes asked for (the stream has to drain for that; once
+// every camera of the scene exists this costs nothing).  `may_build` false (the entry point that allocates nothing):
+// a missing camera is an error.
+static int provide_lightcams(rt_ctx *ctx, uint32_t lc_flags, bool cull, bool may_build)
+{
+    if (ctx->lc_n_built == ctx->lc_have.size()) return RT_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream2));
+    HIP_TRY(hipMemcpy(ctx->h_needed.data(), ctx->lc_needed, ctx->h_needed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> missing;
+    for (size_t k = 0; k < ctx->h_needed.size(); ++k)
+        if (ctx->h_needed[k] && !ctx->lc_have[k]) missing.push_back((int32_t)k);
+    if (missing.empty()) return RT_OK;
+    if (!may_build)
+        return fail(RT_ERR_UNSUPPORTED, "rt_render_noalloc: this frame needs " + std::to_string(missing.size()) + " light camera(s) that are not set "
+                                        "up yet (setting one up allocates); render the frame once with rt_render, or pass RT_FLAG_NO_LIGHTCAM");
+    return build_lightcams(ctx, missing, lc_flags, cull);
 }
 
 // ------------------------------------------------------------------ frame planning
@@ -867,11 +876,13 @@ struct QueuePlan {
     long long need_rays[2] = {0, 0}, need_hits = 0;  // records per buffer
     int hit_buffers = 1;
     bool deferred = false;
+    long long defer_mult = 1;         // lights: the deferred queue of a generation holds every (hit, light) pair
+    size_t deferred_records(int g) const { return (size_t)(hit_cap[g] * defer_mult * N_SHARDS); }
     size_t bytes() const
     {
         size_t b = (size_t)(need_rays[0] + need_rays[1]) * sizeof(RayRec) + (size_t)need_hits * sizeof(HitRec) * hit_buffers;
         if (deferred)
-            for (int g = 0; g < 6; ++g) b += (size_t)(hit_cap[g] * N_SHARDS) * sizeof(HitRec);
+            for (int g = 0; g < 6; ++g) b += deferred_records(g) * sizeof(HitRec);
         return b;
     }
 };
@@ -938,7 +949,7 @@ static int buffers_from_context(rt_ctx *ctx, const QueuePlan &q, size_t n_pixels
         if ((rc = ensure(&ctx->hits[k], &ctx->hit_capacity[k], (size_t)q.need_hits)) != RT_OK) return rc;
     if (q.deferred)
         for (int g = 0; g < 6; ++g)
-            if ((rc = ensure(&ctx->deferred[g], &ctx->deferred_capacity[g], (size_t)(q.hit_cap[g] * N_SHARDS))) != RT_OK) return rc;
+            if ((rc = ensure(&ctx->deferred[g], &ctx->deferred_capacity[g], q.deferred_records(g))) != RT_OK) return rc;
     B.accum = ctx->accum;
     B.rays[0] = ctx->rays[0]; B.rays[1] = ctx->rays[1];
     for (int k = 0; k < 4; ++k) B.hits[k] = ctx->hits[k];
@@ -962,7 +973,7 @@ static size_t scratch_need(const QueuePlan &q, size_t n_pixels)
     b += align256((size_t)q.need_rays[0] * sizeof(RayRec)) + align256((size_t)q.need_rays[1] * sizeof(RayRec));
     b += align256((size_t)q.need_hits * sizeof(HitRec));
     if (q.deferred)
-        for (int g = 0; g < 6; ++g) b += align256((size_t)(q.hit_cap[g] * N_SHARDS) * sizeof(HitRec));
+        for (int g = 0; g < 6; ++g) b += align256(q.deferred_records(g) * sizeof(HitRec));
     return b;
 }
 static void buffers_from_scratch(unsigned char *base, const QueuePlan &q, size_t n_pixels, FrameBuffers &B)
@@ -976,7 +987,7 @@ static void buffers_from_scratch(unsigned char *base, const QueuePlan &q, size_t
     B.rays[1] = reinterpret_cast<RayRec *>(take((size_t)q.need_rays[1] * sizeof(RayRec)));
     B.hits[0] = reinterpret_cast<HitRec *>(take((size_t)q.need_hits * sizeof(HitRec)));
     if (q.deferred)
-        for (int g = 0; g < 6; ++g) B.deferred[g] = reinterpret_cast<HitRec *>(take((size_t)(q.hit_cap[g] * N_SHARDS) * sizeof(HitRec)));
+        for (int g = 0; g < 6; ++g) B.deferred[g] = reinterpret_cast<HitRec *>(take(q.deferred_records(g) * sizeof(HitRec)));
 }
 
 // How a frame is put on the device.
@@ -1009,17 +1020,20 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     if (n_pixels >= (size_t)1 << 31) return fail(RT_ERR_INVALID, "rt_render: more than 2^31 pixels in one part");
 
     const bool may_cull = !(o->flags & RT_FLAG_NO_CULL) && ctx->spheres_inside_root;
+    // light cameras: one per (transparent sphere, light) pair and normal-interpolation mode (the light rays see it), set up
+    // when a frame first asks for them
+    const uint32_t lc_flags = o->flags & RT_FLAG_PHONG_NORMALS;
     {
-        // light cameras: built once per scene (and per normal-interpolation mode, which the light rays see)
-        const uint32_t lc_flags = o->flags & RT_FLAG_PHONG_NORMALS;
         const bool want_lc = !(o->flags & RT_FLAG_NO_LIGHTCAM) && ctx->any_transparent_sphere && !ctx->h_lights.empty();
-        if (want_lc && (!ctx->lc_built || ctx->lc_built_flags != lc_flags)) {
+        if (want_lc && !(ctx->lc_table && ctx->lc_flags == lc_flags)) {
             if (noalloc)
-                return fail(RT_ERR_UNSUPPORTED, "rt_render_noalloc: this scene's light cameras are not built yet for these flags (building "
-                                                "allocates); render one frame with rt_render first, or pass RT_FLAG_NO_LIGHTCAM");
-            int rc = build_lightcams(ctx, lc_flags, may_cull);
+                return fail(RT_ERR_UNSUPPORTED, "rt_render_noalloc: this scene's table of light cameras does not exist yet for these flags "
+                                                "(making it allocates); render one frame with rt_render first, or pass RT_FLAG_NO_LIGHTCAM");
+            int rc = ensure_lightcam_table(ctx, lc_flags);
             if (rc != RT_OK) return rc;
         }
+        ctx->S.lc_table = want_lc ? ctx->lc_table : nullptr;
+        ctx->S.lc_needed = want_lc ? ctx->lc_needed : nullptr;
     }
     FrameParams P{};
     P.S = ctx->S;
@@ -1160,7 +1174,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         if ((rc = ensure(&ctx->accum, &ctx->accum_values, n_pixels * 3)) != RT_OK) return rc;
         if (use_lightcam) {
             const long long bs = batch_chunks < n_chunks ? batch_chunks : n_chunks;
-            fused_defer_cap = (bs * 64 * 2 + N_SHARDS - 1) / N_SHARDS;
+            fused_defer_cap = (bs * 64 * ctx->growth * (P.S.n_lights > 0 ? P.S.n_lights : 1) + N_SHARDS - 1) / N_SHARDS;
             if (fused_defer_cap < 1024) fused_defer_cap = 1024;
             if ((rc = ensure(&ctx->deferred[0], &ctx->deferred_capacity[0], (size_t)(fused_defer_cap * N_SHARDS))) != RT_OK) return rc;
         }
@@ -1183,6 +1197,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             plan_queues(QP, batch_chunks, waves_per_block, max_blocks, fan_out, ctx->growth);
             QP.hit_buffers = overlap ? 4 : (use_pair ? 2 : 1);
             QP.deferred = use_lightcam;
+            QP.defer_mult = P.S.n_lights > 0 ? P.S.n_lights : 1;
             const bool smallest = batch_chunks <= spp;
             int rc = RT_OK;
             if (QP.bytes() > ctx->queue_budget && !smallest) rc = RT_ERR_CAPACITY;
@@ -1209,6 +1224,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 plan_queues(q, bc, waves_per_block, grid, fan_out, ctx->growth);
                 q.hit_buffers = 1;
                 q.deferred = use_lightcam;
+                q.defer_mult = P.S.n_lights > 0 ? P.S.n_lights : 1;
                 if (scratch_need(q, n_pixels) <= RT_NOALLOC_SCRATCH_BYTES && q.need_hits < (1ll << 32)) {
                     const long long waves = (long long)grid * waves_per_block;
                     const long long score = (bc < waves ? bc : waves) * 4 + (bc >= waves ? 1 : 0) * (bc / waves < 1000 ? bc / waves : 1000);
@@ -1294,6 +1310,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.deferred = B.deferred[0];
                 Q.counts = counts;
                 Q.hit_shard_cap = (uint32_t)fused_defer_cap;
+                Q.defer_shard_cap = (uint32_t)fused_defer_cap;
                 Q.generation = 0;
                 Q.chunk_begin = t0;
                 Q.chunk_end = t1;
@@ -1312,6 +1329,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 else hipLaunchKernelGGL((k_fused<true, SHADOW_EXACT>), dim3((unsigned)blocks), dim3(256), lds_bvh, st, P, Q);
                 if (ev) HIP_TRY(hipEventRecord(ev->second, st));
                 if (use_lightcam) {
+                    int lrc = provide_lightcams(ctx, lc_flags, may_cull, true);
+                    if (lrc != RT_OK) return lrc;
                     LightcamQueues L{};
                     L.deferred[0] = B.deferred[0];
                     L.shard_cap[0] = (uint32_t)fused_defer_cap;
@@ -1339,6 +1358,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.in_shard_cap = (uint32_t)ray_cap[g];
                 Q.out_shard_cap = (uint32_t)(g < 5 ? ray_cap[g + 1] : 0);
                 Q.hit_shard_cap = (uint32_t)hit_cap[g];
+                Q.defer_shard_cap = (uint32_t)(hit_cap[g] * QP.defer_mult);
                 Q.hit_stride = all_flat ? 64u : 128u;
                 Q.generation = g;
                 Q.chunk_begin = t0;
@@ -1393,6 +1413,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.in_shard_cap = (uint32_t)ray_cap[g];
                 Q.out_shard_cap = (uint32_t)(g < 5 ? ray_cap[g + 1] : 0);
                 Q.hit_shard_cap = (uint32_t)hit_cap[g];
+                Q.defer_shard_cap = (uint32_t)(hit_cap[g] * QP.defer_mult);
                 Q.hit_stride = all_flat ? 64u : 128u;
                 Q.generation = g;
                 Q.chunk_begin = t0;
@@ -1430,9 +1451,12 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             }
             HIP_TRY(hipStreamWaitEvent(sb, ctx->ev_c[5], 0));
             if (use_lightcam) {
-                // the density queries of all six generations in one launch, after the last shadow pass
+                // the cameras this batch's shading points asked for, then the density queries of all six generations in one
+                // launch, after the last shadow pass
+                int lrc = provide_lightcams(ctx, lc_flags, may_cull, !noalloc);
+                if (lrc != RT_OK) return lrc;
                 LightcamQueues L{};
-                for (int g = 0; g < 6; ++g) { L.deferred[g] = B.deferred[g]; L.shard_cap[g] = (uint32_t)hit_cap[g]; }
+                for (int g = 0; g < 6; ++g) { L.deferred[g] = B.deferred[g]; L.shard_cap[g] = (uint32_t)(hit_cap[g] * QP.defer_mult); }
                 L.counts = counts;
                 hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks_256), dim3(256), 0, sb, P, L);
             }
@@ -1585,7 +1609,7 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "verbose") ctx->dbg.verbose = value != 0;
     else if (n == "leaf_max") ctx->dbg.leaf_max = (int)value;
     else if (n == "split_budget") ctx->dbg.split_budget = (int)value;
-    else if (n == "lightcam_host") { ctx->dbg.lightcam_host = (int)value; ctx->lc_built = false; }
+    else if (n == "lightcam_host") { ctx->dbg.lightcam_host = (int)value; free_lightcams(ctx); }
     else if (n == "fused") ctx->dbg.fused = (int)value;
     else if (n == "overlap") ctx->dbg.overlap = (int)value;
     else if (n == "pair") ctx->dbg.pair = (int)value;

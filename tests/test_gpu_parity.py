@@ -330,12 +330,13 @@ def test_memory_budget_only_changes_the_batching(gpu):
     assert a["stats"]["closest_rays"] == b["stats"]["closest_rays"] and a["stats"]["shadow_rays"] == b["stats"]["shadow_rays"]
 
 
-def test_too_many_light_cameras_is_an_error_not_a_silent_frame(gpu):
-    """More (transparent sphere, light) pairs than the library sets up cameras for: the call fails with a capacity
-    error instead of returning a frame without the light-camera term; RT_FLAG_NO_LIGHTCAM still renders."""
+def test_light_cameras_are_set_up_on_demand(gpu, oracle_mod):
+    """4200 (transparent sphere, light) pairs, of which a frame asks for a fraction: like the reference (Camera.h:417-440)
+    the device sets up the cameras a frame's shading points need, when they need them, and the frame equals the
+    oracle's; a second view adds the cameras it needs to the ones that exist."""
     import os
     import tempfile
-    lines = ["b 0.1 0.1 0.2", "v", "from 0 -12 4", "at 0 0 0", "up 0 0 1", "angle 40", "hither 1", "resolution 48 48"]
+    lines = ["b 0.1 0.1 0.2", "v", "from 0 -12 4", "at 0 0 0", "up 0 0 1", "angle 40", "hither 1", "resolution 56 56", "Z 24"]
     for k in range(5):
         lines.append("l %g 6 9" % (k - 2.0))
     lines.append("f 0.8 0.8 0.8 0.9 0.1 10 0 1")
@@ -352,11 +353,24 @@ def test_too_many_light_cameras_is_an_error_not_a_silent_frame(gpu):
         f.write("\n".join(lines) + "\n")
     s = rt.Scene.load(path)
     gpu.upload(s)
-    with pytest.raises(rt.RtError) as e:
-        gpu.render(s.camera())
-    assert e.value.code == -4 and "light cameras" in str(e.value)
-    g = gpu.render(s.camera(), flags=rt.FLAG_NO_LIGHTCAM)
+    o = oracle_mod.OracleScene(path)
+    ref = o.render(threads=min(16, os.cpu_count() or 1))
+    cams = o.lightcams()
+    o.close()
+    g = gpu.render(s.camera(), flags=rt.FLAG_KEEP_ZERO_WEIGHT)
     assert g["lightcam_mask"].any()
+    assert_frames_match(g, ref, tol=1e-6)
+    assert np.array_equal(g["lightcam_mask"], ref["lightcam_mask"])
+    assert 0 < len(cams) < n * 5
+    assert g["stats"]["lightcam_rays"] == sum(c["light_rays"] for c in cams)     # the same cameras, no more
+    # a narrower view of the same scene: cameras already there are kept, new ones may be added, the frame is the oracle's
+    o = oracle_mod.OracleScene(path)
+    o.set_resolution(40, 72)
+    ref2 = o.render(threads=min(16, os.cpu_count() or 1))
+    o.close()
+    g2 = gpu.render(s.camera(40, 72), flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    assert_frames_match(g2, ref2, tol=1e-6)
+    assert g2["stats"]["lightcam_rays"] >= g["stats"]["lightcam_rays"]
     s.close()
 
 
