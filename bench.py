@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--workload", default="teapot3_8k16", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra RT_FLAG_* bits for the render calls")
+    ap.add_argument("--budget-gib", type=float, default=0.0, help="queue memory budget of the context (0: the library's default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1; gloo (frame staged through host memory) is only for rehearsing "
                          "several ranks on one GPU, where RCCL refuses duplicate devices")
@@ -229,6 +230,8 @@ def main():
     cam = scene.camera(resx, resy)
     resx, resy = cam.resx, cam.resy
     gpu = rt.Renderer(dev_index)
+    if args.budget_gib > 0:
+        gpu.set_memory_budget(int(args.budget_gib * (1 << 30)))
     gpu.upload(scene)
 
     from raytracer_amd.multi import FrameGather

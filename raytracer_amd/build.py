@@ -107,6 +107,19 @@ def build_driver(force=False):
     return DRIVER
 
 
+EXAMPLE = os.path.join(PKG, "bin", "pointer_octree_host")
+
+
+def build_example(force=False):
+    """The compile-tested form of the reference-side integration (examples/pointer_octree_host.cpp)."""
+    src = os.path.join(ROOT, "examples", "pointer_octree_host.cpp")
+    os.makedirs(os.path.dirname(EXAMPLE), exist_ok=True)
+    if force or _newer(EXAMPLE, [src, LIB, os.path.join(ROOT, "include", "raytracer_amd.h")]):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", EXAMPLE, "-L" + PKG,
+              "-lraytracer_amd", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + "/opt/rocm/lib"])
+    return EXAMPLE
+
+
 def build_oracle(force=False):
     odir = os.path.join(ROOT, "oracle")
     if force:
@@ -118,6 +131,7 @@ def build_oracle(force=False):
 def build_all(force=False):
     build_library(force)
     build_driver(force)
+    build_example(force)
     build_oracle(force)
 
 

@@ -65,8 +65,10 @@ std::mutex g_scratch_mutex;
 void *g_scratch_ptr[RT_MAX_DEVICES] = {};       // per device: address of that device's copy of `scratch`
 }  // namespace
 
-// Queue memory one context may take unless rt_set_memory_budget says otherwise.
-#define RT_DEFAULT_QUEUE_BUDGET ((size_t)96 << 30)
+// Queue memory one context may take unless rt_set_memory_budget says otherwise.  The 8K x 16 spp frame by budget
+// (tools/exp_budget.py): 8 GiB 77.8 ms (32 batches), 16 GiB 75.2 (16), 32 GiB 73.7 (8), 48 GiB 72.5 (4), 96 GiB 70.6 (2):
+// every batch pays for the ramp and the tail of its launches again.  The default keeps to a ninth of the card.
+#define RT_DEFAULT_QUEUE_BUDGET ((size_t)32 << 30)
 // Frames of at most this many samples run as one launch per batch (k_fused) instead of the wavefront pipeline.
 #define RT_FUSED_MAX_SAMPLES (1ll << 20)
 
@@ -1162,8 +1164,11 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     // in 16 M batches 81.4 -> 79.1 ms; 512 x 512 frames: teapot-3 0.435 -> 0.389 ms, balls 0.723 -> 0.643, refract
     // 0.504 -> 0.459, against the two-stream overlap they replace).  Larger batches fill the chip for long enough
     // that the paired kernel's few extra register spills cost more than the launches it saves (256 M batches: 70.2 -> 73.4 ms).
-    const bool pair_by_size = batch_chunks * 64 <= (1ll << 24);
-    const bool use_pair = !noalloc && !use_fused && P.S.n_lights > 0 && (ctx->dbg.pair == 1 || (ctx->dbg.pair < 0 && pair_by_size));
+    // (decided for the batch size the memory budget leaves: see the loop below)
+    bool use_pair = false;
+    auto pair_for = [&](long long chunks) {
+        return !noalloc && !use_fused && P.S.n_lights > 0 && (ctx->dbg.pair == 1 || (ctx->dbg.pair < 0 && chunks * 64 <= (1ll << 24)));
+    };
     long long fused_defer_cap = 0;
     if (use_fused) {
         // no ray or hit queues; only the deferred light-camera queries leave the kernel (when that queue is full they are
@@ -1192,6 +1197,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         // The queues of a batch must fit the context's memory budget, and the allocations must succeed: the batch is
         // halved until both hold.
         for (;;) {
+            use_pair = pair_for(batch_chunks);
             overlap = !use_pair && batch_chunks * 64 <= (1ll << 22) && block == 256;
             if (ctx->dbg.overlap >= 0 && !use_pair) overlap = ctx->dbg.overlap != 0;
             plan_queues(QP, batch_chunks, waves_per_block, max_blocks, fan_out, ctx->growth);

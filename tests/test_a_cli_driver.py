@@ -57,3 +57,20 @@ def test_driver_writes_the_reference_image_and_honours_its_flags(tmp_path):
     assert np.array_equal(img, fr["rgb_u8"])
     gpu.close()
     s.close()
+
+
+def test_pointer_octree_host_example(tmp_path):
+    """examples/pointer_octree_host.cpp, the compile-tested form of the reference-side integration: a host that keeps a
+    pointer octree and a primitive vector, flattens them as INTEGRATION.md describes and renders through the C ABI.  Its
+    arrays must equal the front end's (exit code 0) and its image the command-line host's."""
+    example = os.path.join(ROOT, "raytracer_amd", "bin", "pointer_octree_host")
+    assert os.path.exists(example), "build it with python -m raytracer_amd.build"
+    for scene in ("teapot-3", "glass3", "balls"):
+        a, b = str(tmp_path / (scene + "_example.ppm")), str(tmp_path / (scene + "_driver.ppm"))
+        r = subprocess.run([example, rt.scene_path(scene), a], capture_output=True, text=True, timeout=110)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "octree nodes flattened" in r.stdout
+        r2 = subprocess.run([DRIVER, rt.scene_path(scene), b], capture_output=True, text=True, timeout=110)
+        assert r2.returncode == 0, r2.stderr
+        with open(a, "rb") as fa, open(b, "rb") as fb:
+            assert fa.read() == fb.read()

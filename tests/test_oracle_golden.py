@@ -1,10 +1,15 @@
-"""Pins the CPU oracle to what the reference itself holds or produced.
+"""Pins the CPU oracle to what the reference itself holds, and cross-checks it against recorded figures.
 
 * hide.ppm -- the one golden image in the reference checkout (its render of glass.nff,
   including the light-camera caustics): the oracle's glass.nff frame must be
-  byte-identical.
-* golden.json "reference_runs" -- sha256 prefixes, octree sizes and ray counts recorded from
-  a run of the reference binary on tetra-3, teapot-3 (flat and -p), balls and refract.
+  byte-identical.  This is the pin.  It exercises flat triangles, spheres, reflection, refraction and
+  total internal reflection, the ordered shadow query and the light cameras.
+* golden.json "reference_runs" -- sha256 prefixes, octree sizes and ray counts of tetra-3, teapot-3 (flat and -p),
+  balls and refract, recorded from a probe build of the reference's sources against a stand-in for the vector
+  library it needs (absent here) and with the `props` declaration of Driver.cpp:445 hoisted.  That is not the
+  reference as it stands, so these figures pin nothing by themselves; the oracle reproduces all of them, which
+  cross-checks the code paths hide.ppm does not reach (interpolated patch normals, concave ear clipping, the
+  deep octree of balls.nff).
 """
 import gzip
 import hashlib
