@@ -134,6 +134,7 @@ struct FrameParams {
 #define CNT_HITS(g) ((7 + (g)) * N_SHARDS)       // g = 0..5
 #define CNT_DEFER(g) ((13 + (g)) * N_SHARDS)     // g = 0..5: deferred light-camera evaluations
 #define CNT_OVERFLOW (19 * N_SHARDS)
+#define CNT_UNITS (19 * N_SHARDS + 4)            // units of work handed out by a primary pass that shares its chunks out on the device
 #define CNT_WORDS (19 * N_SHARDS + 16)
 
 struct QueueSet {
@@ -146,6 +147,8 @@ struct QueueSet {
     uint32_t defer_shard_cap;    // ... of the deferred queue: hit_shard_cap times the number of lights
     uint32_t hit_stride;         // bytes from one hit record to the next: 128, or 64 when every hit of the scene is a flat triangle's
     int32_t generation;
+    uint32_t unit_chunks;        // PRIMARY only: chunks per unit of work drawn from CNT_UNITS (a power of two), or 0: every block keeps to its own chunks
+    uint32_t unit_mult;          // ... the k-th unit handed out is number (k * unit_mult) mod (number of units); 0: number k
     int64_t chunk_begin, chunk_end;  // PRIMARY only: 64-sample chunks of the primary ordering; a batch begins at a
                                      // block of 8x8 pixels (chunk_begin is a multiple of N*N)
     int64_t block_row0;              // PRIMARY only: row and column, in 8x8-pixel blocks, of the batch's first block

@@ -398,18 +398,16 @@ DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, in
         WC_ADD(wc, lane_leaves);
         const int b = leaf_begin(cur), e = b + leaf_count(cur);
         for (int k = b; k < e; ++k) {
-            double t;
             WC_ADD(wc, lane_prims);
             WC_WAVE(wc, wave_prims);
             if (TRI) {
                 const TriOps tr = load_leaf_tri(S, k);
                 if (tr.prim == parent) continue;
-                t = tri_test_fast(tr, o, d, minT, maxT, maxT);
+                if (tri_any_fast(tr, o, d, minT, maxT)) return true;
             } else {
                 if ((int)(S.bsph_prim[k] & ~RT_SPH_TRANSPARENT) == parent) continue;
-                t = sph_test(&S.bsph[k], o, d, d2, minT, maxT);
+                if (sph_test(&S.bsph[k], o, d, d2, minT, maxT) < maxT) return true;
             }
-            if (t < maxT) return true;
         }
         if (sp == 0) break;
         --sp;

@@ -15,6 +15,8 @@
 // the reference's, as it already must for any parallel sum: a rounding-level difference.)
 // COOP: every lane of the wave calls it together (`active` lanes hold a query); point ranges
 // longer than 24 are then scanned by all 64 lanes.  Without COOP a lane works alone.
+// `overflow` is set to 1 if a lane's stack of pending cells ever fills up (7 siblings per level, 224
+// entries: a tree more than 32 levels deep), so that a sum with a cell missing is never returned silently.
 #define LC_TERMINAL 0x40000000   // stack code: sum this cell's points within range
 #define LC_EXPAND 0x20000000     // stack code: a large, near cell whose children are to be judged
 #ifndef LC_LDS_STACK
@@ -34,7 +36,7 @@ DEV lightcam::Node load_lc_node(const lightcam::Node *n)
 }
 
 template <bool COOP>
-DEV double lc_query(const DevLightCam *table, int cam_index, d3 pos, bool active)
+DEV double lc_query(const DevLightCam *table, int cam_index, d3 pos, bool active, uint32_t *overflow)
 {
     const int lane = (int)(threadIdx.x & 63);
     const DevLightCam cam = table[active ? cam_index : 0];
@@ -100,7 +102,8 @@ DEV double lc_query(const DevLightCam *table, int cam_index, d3 pos, bool active
                     const double size = r->size, hh = size / 2;
                     for (int c = 7; c >= 0; --c) {
                         const int ch = r->child[c];
-                        if (ch < 0 || sp_ >= LC_CAP) continue;
+                        if (ch < 0) continue;
+                        if (sp_ >= LC_CAP) { *overflow = 1u; continue; }   // a cell left out: the frame is reported incomplete
                         const double lox = (c & 1) ? r->cx : r->cx - size / 2;
                         const double loy = (c & 2) ? r->cy : r->cy - size / 2;
                         const double loz = (c & 4) ? r->cz : r->cz - size / 2;
@@ -220,10 +223,9 @@ DEV double lc_query(const DevLightCam *table, int cam_index, d3 pos, bool active
     const double expected = (maxDist * maxDist) / (cam.spw * cam.spw);
     return total / expected;
 }
-DEV double lc_calc_intensity(const DevLightCam *table, int cam_index, d3 pos) { return lc_query<false>(table, cam_index, pos, true); }
-DEV double lc_calc_intensity_wave(const DevLightCam *table, int cam_index, d3 pos, bool active)
+DEV double lc_calc_intensity_wave(const DevLightCam *table, int cam_index, d3 pos, bool active, uint32_t *overflow)
 {
-    return lc_query<true>(table, cam_index, pos, active);
+    return lc_query<true>(table, cam_index, pos, active, overflow);
 }
 
 

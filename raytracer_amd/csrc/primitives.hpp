@@ -65,14 +65,26 @@ DEV TriOps load_tri(const rt_tri_rec *tr)
     return t;
 }
 
-// The same test with its rejections decided before any division.  The four determinants are
-// built from shared 2x2 minors in the reference's association, so detA, X, Y, Z are bit-identical
-// to det3(); a miss is declared early only when the quotient the reference would form is beyond
-// its threshold by more than the rounding of one division (factor 1 +- 2^-40), otherwise the exact
-// sequence above runs.  `tcut` <= maxT: a hit farther than tcut may be reported as maxT (it
-// cannot replace the current nearest hit, and for shadow queries tcut == maxT).
-DEV double tri_test_fast(const TriOps &tr, d3 o, d3 d, double minT, double maxT, double tcut)
+// The same test with its decisions taken before any division wherever that is safe.  The four
+// determinants are built from shared 2x2 minors in the reference's association, so detA, X, Y, Z are
+// bit-identical to det3().  With s = sign(detA) and ad = |detA| (both in a range where no quotient
+// over- or underflows), rounding to nearest is monotonic, so for the quotients the reference forms:
+//   alpha = fl(X/detA) < 0  exactly when sX < 0 (unless the quotient underflows);  alpha > 1  is false for sure
+//   when sX <= ad and true for sure when sX > ad (1 + 2^-40);  likewise beta < 0;
+//   beta > 1 - alpha  is false for sure when sX + sY <= ad (1 - 2^-30) and true for sure when
+//   sX + sY > ad (1 + 2^-30);   t against minT, maxT: for sure outside a factor 1 +- 2^-40 of the threshold.
+// A miss is declared and a hit's barycentric tests are passed on these grounds; only a lane that falls
+// between the sure cases (or out of range) runs the reference's exact sequence of three divisions.
+// TriGate: what the sure cases say about one lane.
+struct TriGate {
+    double detA, Z, ad, sZ;
+    bool miss;       // no intersection, for sure
+    bool inside;     // alpha and beta pass the reference's tests, for sure (t still to be judged)
+    bool early;      // the first barycentric coordinate ruled the triangle out for every lane testing one
+};
+DEV TriGate tri_gate(const TriOps &tr, d3 o, d3 d, double *Xo, double *Yo)
 {
+    TriGate g;
     const d3 v0 = tr.v0, ab = tr.ab, ac = tr.ac;
     const double m3 = ab.y * ac.z - ac.y * ab.z;
     const d3 ae = sub3(v0, o);
@@ -85,19 +97,27 @@ DEV double tri_test_fast(const TriOps &tr, d3 o, d3 d, double minT, double maxT,
     const double ad = fabs(detA);
     const bool ranged = ad > 1e-150 && ad < 1e150;
     const double sX = detA < 0 ? -X : X;
+    g.detA = detA; g.ad = ad; g.Z = 0; g.sZ = 0; g.inside = false;
+    *Xo = X; *Yo = 0;
     // When the first barycentric coordinate alone rules the triangle out for every lane of the wave that is
     // testing one, the other two determinants are not formed (neighbouring rays mostly agree on that).
-    if (__ballot(!(ranged && fabs(X) < 1e150 && (sX < -1e-150 || sX > ad * (1.0 + 0x1p-40)))) == 0) return maxT;
+    g.miss = ranged && fabs(X) < 1e150 && (sX < -1e-150 || sX > ad * (1.0 + 0x1p-40));
+    g.early = __ballot(!g.miss) == 0;
+    if (g.early) return g;
     const double m6 = ab.y * ae.z - ae.y * ab.z;
     const double Y = ab.x * (-m4) + ae.x * m2 + d.x * m6;       // det3(ab, ae, d)
     const double Z = ab.x * (-m5) + ac.x * (-m6) + ae.x * m3;   // det3(ab, ac, ae)
-    if (ranged) {
-        const double sY = detA < 0 ? -Y : Y, sZ = detA < 0 ? -Z : Z;
-        const double up = ad * (1.0 + 0x1p-40);
-        bool miss = (sX < -1e-150) || (sX > up) || (sY < -1e-150) || (sX + sY > ad * (1.0 + 0x1p-30)) ||
-                    (sZ < (minT * ad) * (1.0 - 0x1p-40)) || (sZ > (tcut * ad) * (1.0 + 0x1p-40));
-        if (miss && fabs(X) < 1e150 && fabs(Y) < 1e150 && fabs(Z) < 1e150) return maxT;
-    }
+    const double sY = detA < 0 ? -Y : Y;
+    const bool fin = ranged && fabs(X) < 1e150 && fabs(Y) < 1e150 && fabs(Z) < 1e150;
+    const double sum = sX + sY;
+    g.miss = fin && (sX < -1e-150 || sX > ad * (1.0 + 0x1p-40) || sY < -1e-150 || sum > ad * (1.0 + 0x1p-30));
+    g.inside = fin && sX >= 0 && sX <= ad && sY >= 0 && sum <= ad * (1.0 - 0x1p-30);
+    g.Z = Z; g.sZ = detA < 0 ? -Z : Z;
+    *Yo = Y;
+    return g;
+}
+DEV double tri_exact_tail(double X, double Y, double Z, double detA, double minT, double maxT)
+{
     double alpha = X / detA;
     if (alpha < 0 || alpha > 1) return maxT;
     double beta = Y / detA;
@@ -105,6 +125,45 @@ DEV double tri_test_fast(const TriOps &tr, d3 o, d3 d, double minT, double maxT,
     double t = Z / detA;
     if (t < minT || t > maxT) return maxT;
     return t;
+}
+// Nearest-hit form: returns t or maxT.  `tcut` <= maxT: a hit farther than tcut may be reported as
+// maxT (it cannot replace the current nearest hit).
+DEV double tri_test_fast(const TriOps &tr, d3 o, d3 d, double minT, double maxT, double tcut)
+{
+    double X, Y;
+    const TriGate g = tri_gate(tr, o, d, &X, &Y);
+    if (g.early) return maxT;
+    // a hit for sure farther than tcut, or nearer than minT, needs no quotient either
+    const bool wanted = g.inside && !(g.sZ < (minT * g.ad) * (1.0 - 0x1p-40) || g.sZ > (tcut * g.ad) * (1.0 + 0x1p-40));
+    double t = maxT;
+    const bool exact = !(g.miss || g.inside);
+    if (__ballot(wanted)) {
+        if (wanted) {
+            t = g.Z / g.detA;
+            if (t < minT || t > maxT) t = maxT;
+        }
+    }
+    if (__ballot(exact)) {
+        if (exact) t = tri_exact_tail(X, Y, g.Z, g.detA, minT, maxT);
+    }
+    return t;
+}
+// Any-hit form: is there an intersection with t in [minT, maxT]?  No division unless a lane falls between
+// the sure cases.
+DEV bool tri_any_fast(const TriOps &tr, d3 o, d3 d, double minT, double maxT)
+{
+    double X, Y;
+    const TriGate g = tri_gate(tr, o, d, &X, &Y);
+    if (g.early) return false;
+    const double lo = minT * g.ad, hi = maxT * g.ad;
+    const bool t_out = g.sZ < lo * (1.0 - 0x1p-40) || g.sZ > hi * (1.0 + 0x1p-40);
+    const bool t_in = g.sZ >= lo * (1.0 + 0x1p-40) && g.sZ <= hi * (1.0 - 0x1p-40);
+    bool hit = g.inside && t_in;
+    const bool exact = !(g.miss || (g.inside && (t_in || t_out)));
+    if (__ballot(exact)) {
+        if (exact) hit = tri_exact_tail(X, Y, g.Z, g.detA, minT, maxT) < maxT;
+    }
+    return hit;
 }
 
 // Sphere::intersect (Sphere.h:35-77) without the hit-record update; returns t or maxT.

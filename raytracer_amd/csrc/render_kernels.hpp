@@ -111,7 +111,7 @@ DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, i
 // record and the pushes of the hit and of the secondary rays.
 template <bool PRIMARY, bool BVH>
 DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &smap, long long chunk, int lane, int *stack, bool cull,
-                       WalkCount &wc)
+                       WalkCount &wc, uint32_t shard)
 {
 #define STAMP_SEL (Q.generation)
     bool active;
@@ -194,7 +194,6 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     const bool want_refl = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
     const unsigned long long mask_h = __ballot(want_hit), mask_a = __ballot(want_refr), mask_b = __ballot(want_refl);
     const uint32_t n_h = (uint32_t)__popcll(mask_h), n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b);
-    const uint32_t shard = blockIdx.x & (N_SHARDS - 1);
     uint32_t base_h = 0, base_r = 0;
     if (lane == 0) {
         if (n_h) base_h = atomicAdd(&Q.counts[CNT_HITS(Q.generation) + shard], n_h);
@@ -259,14 +258,58 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
     // generations of small frames fill only a few of the launched blocks)
     if ((long long)blockIdx.x * (blockDim.x >> 6) >= n_chunks) return;
     if (PRIMARY && threadIdx.x == 0) camera_to_lds(P);
+    // (units of work drawn while the pass runs, below: the block's first unit is its own index)
+    volatile int *ring = &s_lds[P.S.lds_ticket_word + 4];
+    if (PRIMARY && threadIdx.x == 0) {
+        const uint32_t nu = Q.unit_chunks ? (uint32_t)((Q.chunk_end - Q.chunk_begin + Q.unit_chunks - 1) / Q.unit_chunks) : 0u;
+        uint32_t id = blockIdx.x;
+        if (Q.unit_mult && id < nu) id = (uint32_t)(((unsigned long long)id * Q.unit_mult) % nu);
+        ring[0] = (int)((1u << 24) | id);
+    }
     STAMP(1);
     fill_node_cache(P.S, BVH);      // ends with the block's barrier
     STAMP(2);
     const bool cull = P.cull_closest != 0;
     WalkCount wc{};
 
-    for (long long chunk = next_chunk(P.S); chunk < n_chunks; chunk = next_chunk(P.S)) {
-        closest_chunk<PRIMARY, BVH>(P, Q, smap, chunk, lane, stack, cull, wc);
+    // A large primary pass (Q.unit_chunks != 0) shares its chunks out while it runs.  Blocks that keep to a fixed share of
+    // the image end as far apart as their shares differ in work (the lower third of the 8K teapot frame: block lifetimes
+    // of 5.3 to 7.0 ms, and the chip idles towards the end of every batch).  Here a block works on units of `unit_chunks`
+    // consecutive chunks: its first unit is its own index, further ones come from a counter in memory, and inside a unit
+    // its waves draw chunks from the ticket in LDS as always.  The wave that draws the middle chunk of a unit fetches the
+    // next unit and leaves it in a ring of four LDS words (tag in the top byte, so a stale word is never taken for the
+    // awaited one); the others wait for that word only if they get there first.  Records go to the shard given by the
+    // unit, not by the block, so that a shard's load does not depend on which blocks were quick.
+    const uint32_t G = PRIMARY ? Q.unit_chunks : 0u, gshift = G ? (uint32_t)(31 - __clz((int)G)) : 0u;
+    const uint32_t n_units = G ? (uint32_t)((n_chunks + G - 1) >> gshift) : 0u;
+    for (;;) {
+        long long chunk;
+        uint32_t shard = blockIdx.x & (N_SHARDS - 1);
+        if (PRIMARY && G) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&s_lds[P.S.lds_ticket_word], 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            const uint32_t j = (uint32_t)t >> gshift, r = (uint32_t)t & (G - 1);
+            int word = 0;
+            if (lane == 0) {
+                if (r == (G >> 1)) {
+                    uint32_t id = gridDim.x + atomicAdd(&Q.counts[CNT_UNITS], 1u);
+                    if (id >= n_units) id = 0xffffffu;
+                    else if (Q.unit_mult) id = (uint32_t)(((unsigned long long)id * Q.unit_mult) % n_units);
+                    ring[(j + 1) & 3] = (int)((((j + 2) & 0xffu) << 24) | id);
+                }
+                while (((uint32_t)(word = ring[j & 3]) >> 24) != ((j + 1) & 0xffu)) __builtin_amdgcn_s_sleep(1);
+            }
+            const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane(word) & 0xffffffu;
+            if (id >= n_units) break;                  // the counter has run past the batch: nothing left for this block
+            chunk = ((long long)id << gshift) + r;
+            if (chunk >= n_chunks) continue;
+            shard = id & (N_SHARDS - 1);
+        } else {
+            chunk = next_chunk(P.S);
+            if (chunk >= n_chunks) break;
+        }
+        closest_chunk<PRIMARY, BVH>(P, Q, smap, chunk, lane, stack, cull, wc, shard);
     }
     STAMP(9);
 #ifdef RT_COUNT
@@ -455,7 +498,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_pair(FramePar
     WalkCount wc{};
     for (long long chunk = next_chunk(P.S); chunk < total; chunk = next_chunk(P.S)) {
         if (chunk < n_s) shadow_chunk<MODE>(P, Qs, sm_s, nl, chunk, stack, cull_s, wc);
-        else closest_chunk<false, BVHC>(P, Qc, sm_c, chunk - n_s, lane, stack, cull_c, wc);
+        else closest_chunk<false, BVHC>(P, Qc, sm_c, chunk - n_s, lane, stack, cull_c, wc, blockIdx.x & (N_SHARDS - 1));
     }
 #ifdef RT_COUNT
     walk_count_flush(wc, 8);
@@ -736,6 +779,7 @@ struct LightcamQueues {
     const HitRec *deferred[6];
     uint32_t shard_cap[6];
     const uint32_t *counts;
+    uint32_t *overflow;          // the frame's "incomplete" word
 };
 __global__ __launch_bounds__(256) void k_lightcam(FrameParams P, LightcamQueues L)
 {
@@ -766,7 +810,7 @@ __global__ __launch_bounds__(256) void k_lightcam(FrameParams P, LightcamQueues 
         bool lit = false;
         d3 local = mk3(0, 0, 0);
         const d3 Pt = ld3(hr->P);
-        const double kfac = lc_calc_intensity_wave(P.S.lc_table, active ? hr->cam : 0, Pt, active);
+        const double kfac = lc_calc_intensity_wave(P.S.lc_table, active ? hr->cam : 0, Pt, active, L.overflow);
         if (active) {
             const rt_light *lt = &P.S.lights[hr->light];
             if (kfac > .01) {
@@ -896,7 +940,8 @@ __global__ __launch_bounds__(256) void k_finalize(const double *accum, long long
     }
 }
 
-// One primitive test per thread with the device functions the kernels use (rt_debug_intersect).
+// One primitive test per thread with the device functions the kernels use (rt_debug_intersect).  Kinds: 0 triangle,
+// 1 its division-sparing form, 2 sphere, 3 node bound, 4 any-hit triangle form, 5 nearest-hit triangle form with cut-off maxT.
 __global__ void k_debug_intersect(int kind, int n, const double *geom, const double *rays, double minT, double maxT, double *out)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -904,7 +949,7 @@ __global__ void k_debug_intersect(int kind, int n, const double *geom, const dou
     const d3 o = ld3(rays + (size_t)i * 6), d = ld3(rays + (size_t)i * 6 + 3);
     double t = maxT;
     d3 nrm = mk3(0, 0, 0);
-    if (kind == 0 || kind == 1) {
+    if (kind == 0 || kind == 1 || kind == 4 || kind == 5) {
         const double *g = geom + (size_t)i * 9;
         rt_tri_rec tr;
         for (int k = 0; k < 3; ++k) { tr.v0[k] = g[k]; tr.ab[k] = g[k] - g[3 + k]; tr.ac[k] = g[k] - g[6 + k]; }   // Triangle.h:40-46
@@ -913,7 +958,9 @@ __global__ void k_debug_intersect(int kind, int n, const double *geom, const dou
         else {
             TriOps ops;
             ops.v0 = ld3(tr.v0); ops.ab = ld3(tr.ab); ops.ac = ld3(tr.ac); ops.prim = 0; ops.key = 0;
-            t = tri_test_fast(ops, o, d, minT, maxT, maxT);
+            if (kind == 1) t = tri_test_fast(ops, o, d, minT, maxT, maxT);
+            else if (kind == 4) t = tri_any_fast(ops, o, d, minT, maxT) ? 0.0 : maxT;       // any-hit form: 0 for a hit
+            else t = tri_test_fast(ops, o, d, minT, 10000000000.0, maxT);                   // nearest-hit form, maxT is its cut-off
         }
     } else if (kind == 2) {
         const double *g = geom + (size_t)i * 4;

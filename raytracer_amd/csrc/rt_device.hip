@@ -68,6 +68,7 @@ void *g_scratch_ptr[RT_MAX_DEVICES] = {};       // per device: address of that d
 // Queue memory one context may take unless rt_set_memory_budget says otherwise.  The 8K x 16 spp frame by budget
 // (tools/exp_budget.py): 8 GiB 77.8 ms (32 batches), 16 GiB 75.2 (16), 32 GiB 73.7 (8), 48 GiB 72.5 (4), 96 GiB 70.6 (2):
 // every batch pays for the ramp and the tail of its launches again.  The default keeps to a ninth of the card.
+#define RT_TOTALS_WORDS 16     // per-frame statistics rolled up on the device (k_collect_counts)
 #define RT_DEFAULT_QUEUE_BUDGET ((size_t)32 << 30)
 // Frames of at most this many samples run as one launch per batch (k_fused) instead of the wavefront pipeline.
 #define RT_FUSED_MAX_SAMPLES (1ll << 20)
@@ -82,6 +83,7 @@ struct DebugOptions {
     int leaf_max = 0, split_budget = -1;   // hierarchy builder (accel::Options), read at the next upload
     int lightcam_host = 0;          // 1: the light cameras' point octrees are built by the host builder (lightcam_build.cpp)
     int fused = -1;                 // 1: always the one-launch kernel, 0: never, -1: by frame size
+    int units = 1;                  // 0: the primary pass never shares its chunks out on the device (every block keeps to a fixed share)
     int overlap = -1;               // 1: shadow passes on the second stream beside the next closest-hit pass, 0: one stream, -1: by batch size
     int pair = -1;                  // 1: shadow pass g and closest-hit pass g+1 in one launch, 0: a launch each, -1: default (paired)
 };
@@ -217,7 +219,7 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
     HIP_TRY(hipEventCreate(&ctx->ev_begin));
     HIP_TRY(hipEventCreate(&ctx->ev_end));
     HIP_TRY(hipMalloc((void **)&ctx->counts, 2 * CNT_WORDS * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&ctx->totals, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&ctx->totals, RT_TOTALS_WORDS * sizeof(unsigned long long)));
     {
         // a block of the traversal kernels may use all of a compute unit's LDS
         const int lds_max = (int)ctx->lds_per_cu;
@@ -279,10 +281,10 @@ extern "C" int rt_destroy(rt_ctx *ctx)
 extern "C" int rt_debug_intersect(rt_ctx *ctx, int32_t kind, int32_t n, const double *geom, const double *rays, double minT,
                                   double maxT, double *out)
 {
-    if (!ctx || !geom || !rays || !out || n < 0 || kind < 0 || kind > 3) return fail(RT_ERR_INVALID, "rt_debug_intersect: bad argument");
+    if (!ctx || !geom || !rays || !out || n < 0 || kind < 0 || kind > 5) return fail(RT_ERR_INVALID, "rt_debug_intersect: bad argument");
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t gdoubles = (size_t)n * (kind <= 1 ? 9 : 4);
+    const size_t gdoubles = (size_t)n * ((kind <= 1 || kind >= 4) ? 9 : 4);
     double *d_geom = nullptr, *d_rays = nullptr, *d_out = nullptr;
     int rc = RT_OK;
     if (hipMalloc((void **)&d_geom, gdoubles * 8) != hipSuccess || hipMalloc((void **)&d_rays, (size_t)n * 48) != hipSuccess ||
@@ -876,20 +878,24 @@ struct QueuePlan {
     long long blocks0 = 0;            // grid of a full primary pass
     long long hit_cap[6] = {}, ray_cap[7] = {};      // records per shard
     long long need_rays[2] = {0, 0}, need_hits = 0;  // records per buffer
+    uint32_t unit_chunks = 0;         // the primary pass shares its chunks out in units of this many (0: fixed shares)
     int hit_buffers = 1;
+    long long hit_stride = sizeof(HitRec);   // bytes per hit record: 64 when every hit of the scene is a flat triangle's
+    long long hit_slots() const { return (need_hits * hit_stride + (long long)sizeof(HitRec) - 1) / (long long)sizeof(HitRec); }   // in whole HitRec
     bool deferred = false;
     long long defer_mult = 1;         // lights: the deferred queue of a generation holds every (hit, light) pair
     size_t deferred_records(int g) const { return (size_t)(hit_cap[g] * defer_mult * N_SHARDS); }
     size_t bytes() const
     {
-        size_t b = (size_t)(need_rays[0] + need_rays[1]) * sizeof(RayRec) + (size_t)need_hits * sizeof(HitRec) * hit_buffers;
+        size_t b = (size_t)(need_rays[0] + need_rays[1]) * sizeof(RayRec) + (size_t)hit_slots() * sizeof(HitRec) * hit_buffers;
         if (deferred)
             for (int g = 0; g < 6; ++g) b += deferred_records(g) * sizeof(HitRec);
         return b;
     }
 };
 
-static void plan_queues(QueuePlan &q, long long batch_chunks, int waves_per_block, int max_blocks, long long fan_out, long long growth)
+static void plan_queues(QueuePlan &q, long long batch_chunks, int waves_per_block, int max_blocks, long long fan_out, long long growth,
+                        bool units_allowed = true)
 {
     q.batch_chunks = batch_chunks;
     q.max_blocks = max_blocks;
@@ -901,6 +907,14 @@ static void plan_queues(QueuePlan &q, long long batch_chunks, int waves_per_bloc
     const long long w0 = blocks0 * waves_per_block, wps0 = ((blocks0 + N_SHARDS - 1) / N_SHARDS) * waves_per_block;
     q.ray_cap[0] = 0;
     q.hit_cap[0] = ((batch_chunks + w0 - 1) / w0) * 64 * wps0;
+    // A primary pass with many chunks per wave hands them out in units while it runs (k_closest); a unit's records go to
+    // the shard given by its number, so a shard holds at most its share of the units whichever blocks worked on them.
+    q.unit_chunks = 0;
+    if (units_allowed && batch_chunks >= 16 * w0 && blocks0 == max_blocks) {
+        q.unit_chunks = 64;
+        const long long units = (batch_chunks + q.unit_chunks - 1) / q.unit_chunks;
+        q.hit_cap[0] = ((units + N_SHARDS - 1) / N_SHARDS) * q.unit_chunks * 64;
+    }
     const long long ray_limit = q.hit_cap[0] * (growth < 1 ? 1 : growth);
     q.ray_cap[1] = q.hit_cap[0] * fan_out < ray_limit ? q.hit_cap[0] * fan_out : ray_limit;
     for (int g = 1; g < 6; ++g) {
@@ -938,7 +952,7 @@ struct FrameBuffers {
     HitRec *hits[4] = {nullptr, nullptr, nullptr, nullptr};
     HitRec *deferred[6] = {};
     uint32_t *counts = nullptr;                 // 2 * CNT_WORDS
-    unsigned long long *totals = nullptr;       // 16
+    unsigned long long *totals = nullptr;       // RT_TOTALS_WORDS
 };
 
 static int buffers_from_context(rt_ctx *ctx, const QueuePlan &q, size_t n_pixels, FrameBuffers &B)
@@ -948,7 +962,7 @@ static int buffers_from_context(rt_ctx *ctx, const QueuePlan &q, size_t n_pixels
     if ((rc = ensure(&ctx->rays[0], &ctx->ray_capacity[0], (size_t)q.need_rays[0])) != RT_OK) return rc;
     if ((rc = ensure(&ctx->rays[1], &ctx->ray_capacity[1], (size_t)q.need_rays[1])) != RT_OK) return rc;
     for (int k = 0; k < q.hit_buffers; ++k)
-        if ((rc = ensure(&ctx->hits[k], &ctx->hit_capacity[k], (size_t)q.need_hits)) != RT_OK) return rc;
+        if ((rc = ensure(&ctx->hits[k], &ctx->hit_capacity[k], (size_t)q.hit_slots())) != RT_OK) return rc;
     if (q.deferred)
         for (int g = 0; g < 6; ++g)
             if ((rc = ensure(&ctx->deferred[g], &ctx->deferred_capacity[g], q.deferred_records(g))) != RT_OK) return rc;
@@ -971,9 +985,9 @@ static void release_queues(rt_ctx *ctx)
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t scratch_need(const QueuePlan &q, size_t n_pixels)
 {
-    size_t b = align256(n_pixels * 3 * sizeof(double)) + align256(2 * CNT_WORDS * sizeof(uint32_t)) + align256(16 * sizeof(unsigned long long));
+    size_t b = align256(n_pixels * 3 * sizeof(double)) + align256(2 * CNT_WORDS * sizeof(uint32_t)) + align256(RT_TOTALS_WORDS * sizeof(unsigned long long));
     b += align256((size_t)q.need_rays[0] * sizeof(RayRec)) + align256((size_t)q.need_rays[1] * sizeof(RayRec));
-    b += align256((size_t)q.need_hits * sizeof(HitRec));
+    b += align256((size_t)q.hit_slots() * sizeof(HitRec));
     if (q.deferred)
         for (int g = 0; g < 6; ++g) b += align256(q.deferred_records(g) * sizeof(HitRec));
     return b;
@@ -984,10 +998,10 @@ static void buffers_from_scratch(unsigned char *base, const QueuePlan &q, size_t
     auto take = [&](size_t bytes) { unsigned char *p = base + off; off += align256(bytes); return p; };
     B.accum = reinterpret_cast<double *>(take(n_pixels * 3 * sizeof(double)));
     B.counts = reinterpret_cast<uint32_t *>(take(2 * CNT_WORDS * sizeof(uint32_t)));
-    B.totals = reinterpret_cast<unsigned long long *>(take(16 * sizeof(unsigned long long)));
+    B.totals = reinterpret_cast<unsigned long long *>(take(RT_TOTALS_WORDS * sizeof(unsigned long long)));
     B.rays[0] = reinterpret_cast<RayRec *>(take((size_t)q.need_rays[0] * sizeof(RayRec)));
     B.rays[1] = reinterpret_cast<RayRec *>(take((size_t)q.need_rays[1] * sizeof(RayRec)));
-    B.hits[0] = reinterpret_cast<HitRec *>(take((size_t)q.need_hits * sizeof(HitRec)));
+    B.hits[0] = reinterpret_cast<HitRec *>(take((size_t)q.hit_slots() * sizeof(HitRec)));
     if (q.deferred)
         for (int g = 0; g < 6; ++g) B.deferred[g] = reinterpret_cast<HitRec *>(take(q.deferred_records(g) * sizeof(HitRec)));
 }
@@ -1146,7 +1160,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     }
     // every traversal kernel gets the same layout (the octree-walk variants use the tables only)
     const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int) +
-                           (size_t)P.S.btri_cached * 80 + lds_tables + 128 + 16;
+                           (size_t)P.S.btri_cached * 80 + lds_tables + 128 + 32;
     const size_t lds_closest = lds_bvh;
     const size_t lds_shadow = lds_bvh;
     const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
@@ -1196,17 +1210,22 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         // stream a single buffer serves every pass.
         // The queues of a batch must fit the context's memory budget, and the allocations must succeed: the batch is
         // halved until both hold.
+        // Over budget, the frame is cut into as many batches as the budget allows if bytes go with the batch size,
+        // and at least one more than now; when an allocation fails, the batch is halved.
         for (;;) {
             use_pair = pair_for(batch_chunks);
             overlap = !use_pair && batch_chunks * 64 <= (1ll << 22) && block == 256;
             if (ctx->dbg.overlap >= 0 && !use_pair) overlap = ctx->dbg.overlap != 0;
-            plan_queues(QP, batch_chunks, waves_per_block, max_blocks, fan_out, ctx->growth);
+            plan_queues(QP, batch_chunks, waves_per_block, max_blocks, fan_out, ctx->growth, ctx->dbg.units != 0);
             QP.hit_buffers = overlap ? 4 : (use_pair ? 2 : 1);
+            QP.hit_stride = all_flat ? 64 : (long long)sizeof(HitRec);
             QP.deferred = use_lightcam;
             QP.defer_mult = P.S.n_lights > 0 ? P.S.n_lights : 1;
             const bool smallest = batch_chunks <= spp;
+            const size_t plan_bytes = QP.bytes();
+            const bool over_budget = plan_bytes > ctx->queue_budget && !smallest;
             int rc = RT_OK;
-            if (QP.bytes() > ctx->queue_budget && !smallest) rc = RT_ERR_CAPACITY;
+            if (over_budget) rc = RT_ERR_CAPACITY;
             else if (QP.need_rays[0] >= (1ll << 32) || QP.need_rays[1] >= (1ll << 32) || QP.need_hits >= (1ll << 32)) rc = RT_ERR_CAPACITY;
             else {
                 rc = buffers_from_context(ctx, QP, n_pixels, B);
@@ -1214,8 +1233,18 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             }
             if (rc == RT_OK) break;
             if (smallest) return rc == RT_ERR_CAPACITY ? fail(RT_ERR_CAPACITY, "rt_render: the queues of the smallest batch exceed the memory budget") : rc;
-            batch_chunks = even_batches(n_chunks, (batch_chunks + 1) / 2, spp);
+            long long next = (batch_chunks + 1) / 2;
+            if (over_budget && ctx->batch_override <= 0) {
+                // the number of batches the budget allows if bytes go with the batch size, and at least one more than now
+                const long long now = (n_chunks + batch_chunks - 1) / batch_chunks;
+                long long want = (long long)((double)now * (double)plan_bytes / (double)ctx->queue_budget) + 1;
+                if (want <= now) want = now + 1;
+                next = (n_chunks + want - 1) / want;
+                if (next >= batch_chunks) next = batch_chunks - spp;
+            }
+            batch_chunks = even_batches(n_chunks, next, spp);
         }
+
     } else if (local_rows > 0) {
         // The static scratch holds the accumulation frame, the counters and one batch's queues.  Among the grids of
         // queued passes that fit, the one that keeps most waves busy wins: a smaller grid has smaller per-shard floors.
@@ -1227,7 +1256,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             long long bc = even_batches(n_chunks, wanted_batch_chunks, spp);
             for (;;) {
                 QueuePlan q;
-                plan_queues(q, bc, waves_per_block, grid, fan_out, ctx->growth);
+                plan_queues(q, bc, waves_per_block, grid, fan_out, ctx->growth, ctx->dbg.units != 0);
                 q.hit_buffers = 1;
                 q.deferred = use_lightcam;
                 q.defer_mult = P.S.n_lights > 0 ? P.S.n_lights : 1;
@@ -1257,7 +1286,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
 
     hipStream_t st = ctx->stream;
     HIP_TRY(hipEventRecord(ctx->ev_begin, st));
-    HIP_TRY(hipMemsetAsync(B.totals, 0, 16 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(B.totals, 0, RT_TOTALS_WORDS * sizeof(unsigned long long), st));
     ctx->ev_closest_used = ctx->ev_shadow_used = ctx->ev_pair_used = 0;
     ctx->pending_closest_per_batch = use_pair ? 1 : 6;
     ctx->pending_flags = o->flags;
@@ -1341,6 +1370,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     L.deferred[0] = B.deferred[0];
                     L.shard_cap[0] = (uint32_t)fused_defer_cap;
                     L.counts = counts;
+                    L.overflow = &counts[CNT_OVERFLOW];
                     hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks_256), dim3(256), 0, st, P, L);
                 }
                 hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, counts, B.totals, P.S.n_lights);
@@ -1367,6 +1397,20 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.defer_shard_cap = (uint32_t)(hit_cap[g] * QP.defer_mult);
                 Q.hit_stride = all_flat ? 64u : 128u;
                 Q.generation = g;
+                Q.unit_chunks = g == 0 ? QP.unit_chunks : 0u;
+                Q.unit_mult = 0;
+                if (g == 0 && QP.unit_chunks) {
+                    // Units are handed out in the order (k * m) mod n, m near 0.618 n and sharing no factor with n:
+                    // units worked on at the same time then lie all over the batch's rows, so the parts of the image
+                    // where every sample hits (and writes its records) are mixed with the parts where few do, instead of
+                    // the whole chip sweeping through them together (8K teapot frame in one batch: primary pass 24.2 ->
+                    // 20.9 ms, in two batches 21.3 -> 20.8 ms).
+                    const unsigned long long nu = (unsigned long long)((t1 - t0 + QP.unit_chunks - 1) / QP.unit_chunks);
+                    unsigned long long a = (unsigned long long)((double)nu * 0.6180339887) | 1ull;
+                    auto gcd = [](unsigned long long x, unsigned long long y) { while (y) { unsigned long long r = x % y; x = y; y = r; } return x; };
+                    while (a > 1 && gcd(a, nu) != 1) a += 2;
+                    Q.unit_mult = (uint32_t)(a % (nu ? nu : 1));
+                }
                 Q.chunk_begin = t0;
                 Q.chunk_end = t1;
                 Q.block_row0 = (t0 / (N * N)) / P.blocks_x;
@@ -1422,6 +1466,20 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.defer_shard_cap = (uint32_t)(hit_cap[g] * QP.defer_mult);
                 Q.hit_stride = all_flat ? 64u : 128u;
                 Q.generation = g;
+                Q.unit_chunks = g == 0 ? QP.unit_chunks : 0u;
+                Q.unit_mult = 0;
+                if (g == 0 && QP.unit_chunks) {
+                    // Units are handed out in the order (k * m) mod n, m near 0.618 n and sharing no factor with n:
+                    // units worked on at the same time then lie all over the batch's rows, so the parts of the image
+                    // where every sample hits (and writes its records) are mixed with the parts where few do, instead of
+                    // the whole chip sweeping through them together (8K teapot frame in one batch: primary pass 24.2 ->
+                    // 20.9 ms, in two batches 21.3 -> 20.8 ms).
+                    const unsigned long long nu = (unsigned long long)((t1 - t0 + QP.unit_chunks - 1) / QP.unit_chunks);
+                    unsigned long long a = (unsigned long long)((double)nu * 0.6180339887) | 1ull;
+                    auto gcd = [](unsigned long long x, unsigned long long y) { while (y) { unsigned long long r = x % y; x = y; y = r; } return x; };
+                    while (a > 1 && gcd(a, nu) != 1) a += 2;
+                    Q.unit_mult = (uint32_t)(a % (nu ? nu : 1));
+                }
                 Q.chunk_begin = t0;
                 Q.chunk_end = t1;
                 Q.block_row0 = (t0 / (N * N)) / P.blocks_x;
@@ -1464,6 +1522,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 LightcamQueues L{};
                 for (int g = 0; g < 6; ++g) { L.deferred[g] = B.deferred[g]; L.shard_cap[g] = (uint32_t)(hit_cap[g] * QP.defer_mult); }
                 L.counts = counts;
+                L.overflow = &counts[CNT_OVERFLOW];
                 hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks_256), dim3(256), 0, sb, P, L);
             }
             hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, sb, counts, B.totals, P.S.n_lights);
@@ -1498,7 +1557,7 @@ extern "C" int rt_sync(rt_ctx *ctx, rt_stats *stats)
     HIP_TRY(hipSetDevice(ctx->device));
     ctx->pending = false;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    unsigned long long tot[16];
+    unsigned long long tot[RT_TOTALS_WORDS];
     HIP_TRY(hipMemcpy(tot, ctx->pending_totals, sizeof tot, hipMemcpyDeviceToHost));
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
@@ -1617,6 +1676,7 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "split_budget") ctx->dbg.split_budget = (int)value;
     else if (n == "lightcam_host") { ctx->dbg.lightcam_host = (int)value; free_lightcams(ctx); }
     else if (n == "fused") ctx->dbg.fused = (int)value;
+    else if (n == "units") ctx->dbg.units = (int)value;
     else if (n == "overlap") ctx->dbg.overlap = (int)value;
     else if (n == "pair") ctx->dbg.pair = (int)value;
     else if (n == "queue_growth") ctx->growth = value < 1 ? 1 : (value > 32 ? 32 : (int)value);

@@ -276,6 +276,29 @@ def test_paired_and_separate_passes_agree(gpu, oracle_frame, scene, res):
         assert np.array_equal(g["lightcam_mask"], o["lightcam_mask"])
 
 
+def test_primary_pass_in_units_drawn_while_it_runs(gpu, oracle_frame):
+    """A primary pass with many chunks per wave hands its chunks out in units while it runs (a counter in memory, a
+    permuted order, records sharded by unit) instead of giving every block a fixed share: the same frame and ray counts
+    both ways, and against the oracle."""
+    scene, res, n = "teapot-3", (2048, 1040), 2          # 8.5 M samples: above the threshold for units
+    s = load_scene(gpu, scene)
+    cam = s.camera(*res)
+    frames = []
+    for units in (1, 0):
+        gpu.set_option("units", units)
+        try:
+            frames.append(gpu.render(cam, num_samples=n, flags=rt.FLAG_KEEP_ZERO_WEIGHT))
+        finally:
+            gpu.set_option("units", 1)
+    o = oracle_frame(scene, res=res, num_samples=n)
+    for g in frames:
+        assert_frames_match(g, o, tol=1e-6)
+        assert g["stats"]["closest_rays"] == o["counters"]["closest_rays"]
+        assert g["stats"]["shadow_rays"] == o["counters"]["shadow_rays"]
+    assert np.array_equal(frames[0]["rgb_u8"], frames[1]["rgb_u8"])
+    assert frames[0]["stats"]["rays_per_generation"] == frames[1]["stats"]["rays_per_generation"]
+
+
 @pytest.mark.parametrize("scene", ["glass3", "glass"])
 def test_one_launch_kernel_with_light_cameras(gpu, oracle_frame, scene):
     s = load_scene(gpu, scene)

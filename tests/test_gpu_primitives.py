@@ -9,6 +9,7 @@ from oracle import binding as ob
 
 pytestmark = pytest.mark.gpu
 MIN_T, MAX_T = 0.01, 1e10
+CUT = 5.0          # an upper limit in the middle of the hit distances of the random pairs
 
 
 @pytest.fixture(scope="module")
@@ -44,6 +45,49 @@ def test_triangle_tests_match_the_oracle_bit_for_bit(gpu):
     assert same_bits(fast[:, 0], ref[:, 0])
 
 
+def borderline_rays(rng, tri, n):
+    """Rays aimed at points ON the edges and vertices of their triangles (alpha = 0, beta = 0, alpha + beta = 1 up to
+    rounding) and rays whose hit distance is minT or the upper limit up to rounding: where a decision taken without
+    the quotient could differ from the reference's."""
+    v = tri.reshape(n, 3, 3)
+    w = rng.dirichlet([1, 1, 1], size=n)
+    which = rng.integers(0, 6, size=n)
+    w[which == 0, 0] = 0; w[which == 1, 1] = 0; w[which == 2, 2] = 0     # on an edge
+    w[which == 3] = [1, 0, 0]                                              # a vertex
+    w /= w.sum(axis=1, keepdims=True)
+    target = np.einsum("nk,nkj->nj", w, v)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dist = rng.uniform(0.5, 9.0, size=n)
+    dist[which == 4] = MIN_T                                               # t = minT up to rounding
+    dist[which == 5] = CUT                                                 # t = the upper limit used below
+    return np.hstack([target - d * dist[:, None], d])
+
+
+def test_triangle_forms_without_quotients_decide_as_the_oracle(gpu):
+    """The any-hit and nearest-hit forms decide from the determinants when that is safe: same decisions, and for the
+    nearest-hit form the same t bit for bit, on random pairs and on pairs that sit on the decision boundaries."""
+    rng = np.random.default_rng(11)
+    n = 200000
+    tri = rng.uniform(-1, 1, size=(n, 9))
+    sets = {"random": random_rays(rng, n, tri.reshape(n, 3, 3).mean(axis=1), 0.4), "borderline": borderline_rays(rng, tri, n)}
+    for name, rays in sets.items():
+        for max_t in (MAX_T, CUT):
+            ref = ob.test_batch(0, tri, rays, MIN_T, max_t)[:, 0]
+            hit = ref < max_t
+            assert 0.05 < hit.mean() < 0.95, (name, hit.mean())
+            fast = gpu.debug_intersect(1, tri, rays, MIN_T, max_t)[:, 0]
+            assert same_bits(fast, ref), (name, max_t)
+            anyhit = gpu.debug_intersect(4, tri, rays, MIN_T, max_t)[:, 0]
+            assert np.array_equal(anyhit == 0.0, hit) and np.array_equal(anyhit == max_t, ~hit), (name, max_t)
+        # nearest-hit form with a cut-off: exact up to the cut-off, beyond it either the exact t or "nothing"
+        full = ob.test_batch(0, tri, rays, MIN_T, MAX_T)[:, 0]
+        cut = gpu.debug_intersect(5, tri, rays, MIN_T, CUT)[:, 0]
+        near = full <= CUT
+        assert same_bits(cut[near], full[near]), name
+        assert np.all((cut[~near] == full[~near]) | (cut[~near] == MAX_T)), name
+
+
 def test_triangle_edge_cases(gpu):
     tri = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]] * 8, dtype=np.float64)
     rays = np.array([
@@ -59,16 +103,19 @@ def test_triangle_edge_cases(gpu):
     tri[7] *= 1e-3                      # a tiny triangle, scaled ray target
     rays[7, :2] *= 1e-3
     ref = ob.test_batch(0, tri, rays, MIN_T, MAX_T)
-    for kind in (0, 1):
+    for kind in (0, 1, 5):
         got = gpu.debug_intersect(kind, tri, rays, MIN_T, MAX_T)
         assert same_bits(got[:, 0], ref[:, 0]), (kind, got[:, 0], ref[:, 0])
+    assert np.array_equal(gpu.debug_intersect(4, tri, rays, MIN_T, MAX_T)[:, 0] == 0.0, ref[:, 0] < MAX_T)
     assert ref[0, 0] == MAX_T and ref[1, 0] == 2.0 and ref[2, 0] == MAX_T and ref[6, 0] == 2.0
     # degenerate triangles (zero area, repeated vertices) never hit and never trap
     deg = np.array([[0, 0, 0, 1, 1, 1, 2, 2, 2], [1, 2, 3, 1, 2, 3, 1, 2, 3]], dtype=np.float64)
     drays = np.array([[0, 0, 5, 0.1, 0.2, -1], [0, 0, 5, 0.2, 0.4, -0.4]], dtype=np.float64)
     ref = ob.test_batch(0, deg, drays, MIN_T, MAX_T)
-    for kind in (0, 1):
+    for kind in (0, 1, 5):
         assert same_bits(gpu.debug_intersect(kind, deg, drays, MIN_T, MAX_T)[:, 0], ref[:, 0])
+    # (the all-equal triangle yields t = NaN in the reference; a shadow query asks "t < maxT", which NaN is not)
+    assert np.array_equal(gpu.debug_intersect(4, deg, drays, MIN_T, MAX_T)[:, 0] == 0.0, ref[:, 0] < MAX_T)
 
 
 def test_sphere_tests_match_the_oracle_bit_for_bit(gpu):
