@@ -506,6 +506,107 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_pair(FramePar
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// A small frame as ONE launch of blocks that each render their own samples through all generations.
+//
+// Pass by pass over the whole frame, a frame of a few hundred thousand samples is a chain of launches each as long as
+// its slowest wave (a wave whose rays graze the geometry walks 2.5 times as long as the median wave), and the other
+// four thousand waves wait for it seven times over.  Here a block takes a fixed run of primary chunks and keeps what
+// they spawn to itself: its hit and ray queues are its own slices of the queue buffers, their counters live in LDS
+// (the same counter layout, shard 0 only, so the pass functions run unchanged), and the passes -- primary, then the
+// shadow pass of generation g together with the closest-hit pass of generation g+1, as in k_pair -- are separated by
+// the block's barrier only.  A slow wave then holds up the fifteen other waves of its block for one pass, not the chip,
+// and blocks drift apart freely.  Rays are still regrouped into full waves, per block.  At the end the block adds its
+// counters to the frame's (shard 0), for the statistics and the overflow report.
+// Only for scenes whose shadow queries take the hierarchies (no deferred light-camera queries, which go through the
+// frame's sharded queues).
+struct LocalPlan {
+    uint32_t chunks_per_block;   // primary chunks of a block
+    uint32_t ray_cap, hit_cap;   // records of one block in one ray buffer / the hit buffer of one parity
+    int32_t lds_counts_word;     // first LDS word of the block's CNT_WORDS counters
+    RayRec *rays[2];             // by generation parity
+    HitRec *hits[2];
+    uint32_t *frame_counts;      // the frame's counters
+};
+template <int MODE>
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FrameParams P, QueueSet Q0, LocalPlan L)
+{
+    int *stack = &s_lds[threadIdx.x];
+    const int lane = (int)(threadIdx.x & 63);
+    const long long n_chunks = Q0.chunk_end - Q0.chunk_begin;
+    // a block's primary chunks lie a grid apart, all over the frame: every block then gets its share of the parts of
+    // the image where the trees are deep
+    if ((long long)blockIdx.x >= n_chunks) return;
+    const uint32_t my_chunks = (uint32_t)((n_chunks - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(&s_lds[L.lds_counts_word]);
+    for (int i = (int)threadIdx.x; i < CNT_WORDS; i += (int)blockDim.x) cnt[i] = 0u;
+    if (threadIdx.x == 0) camera_to_lds(P);
+    fill_node_cache(P.S, true);      // ends with the block's barrier, ticket at zero
+    const bool cull_s = P.cull_shadow != 0, cull_c = P.cull_closest != 0;
+    const uint32_t nl = (uint32_t)P.S.n_lights;
+    const size_t hit_bytes = (size_t)L.hit_cap * Q0.hit_stride;
+    WalkCount wc{};
+    auto queue_set = [&](int g) {
+        QueueSet Q = Q0;
+        Q.rays_in = L.rays[g & 1] + (size_t)blockIdx.x * L.ray_cap;
+        Q.rays_out = L.rays[(g + 1) & 1] + (size_t)blockIdx.x * L.ray_cap;
+        Q.hits = reinterpret_cast<HitRec *>(reinterpret_cast<char *>(L.hits[g & 1]) + (size_t)blockIdx.x * hit_bytes);
+        Q.counts = cnt;
+        Q.in_shard_cap = L.ray_cap;
+        Q.out_shard_cap = g < 5 ? L.ray_cap : 0u;
+        Q.hit_shard_cap = L.hit_cap;
+        Q.generation = g;
+        Q.unit_chunks = 0;
+        return Q;
+    };
+    auto local_map = [&](uint32_t records, uint32_t cap, uint32_t per_record) {
+        ShardMap m;                       // one shard, number 0
+        const uint32_t n = records < cap ? records : cap;
+        m.items = lane == 0 ? n * per_record : 0u;
+        m.first = 0u;
+        m.total = (n * per_record + 63u) >> 6;
+        return m;
+    };
+    // primary pass
+    {
+        const QueueSet Qc = queue_set(0);
+        ShardMap none;
+        none.items = none.first = none.total = 0u;
+        for (;;) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&s_lds[P.S.lds_ticket_word], 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if ((uint32_t)t >= my_chunks) break;
+            closest_chunk<true, true>(P, Qc, none, (long long)blockIdx.x + (long long)t * gridDim.x, lane, stack, cull_c, wc, 0u);
+        }
+    }
+    // S_g + C_g+1 for g = 0..4, then S_5
+    for (int g = 0; g < 6; ++g) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_lds[P.S.lds_ticket_word] = 0;
+        __syncthreads();
+        const QueueSet Qs = queue_set(g), Qc = queue_set(g < 5 ? g + 1 : 5);
+        const ShardMap sm_s = local_map(nl ? cnt[CNT_HITS(g)] : 0u, L.hit_cap, nl);
+        const ShardMap sm_c = local_map(g < 5 ? cnt[CNT_RAYS(g + 1)] : 0u, L.ray_cap, 1u);
+        const uint32_t n_s = sm_s.total, total = n_s + sm_c.total;
+        if (total == 0) break;           // the same for every thread of the block: nothing left in this block's trees
+        for (;;) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&s_lds[P.S.lds_ticket_word], 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if ((uint32_t)t >= total) break;
+            if ((uint32_t)t < n_s) shadow_chunk<MODE>(P, Qs, sm_s, nl, (long long)t, stack, cull_s, wc);
+            else closest_chunk<false, true>(P, Qc, sm_c, (long long)((uint32_t)t - n_s), lane, stack, cull_c, wc, 0u);
+        }
+    }
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < CNT_WORDS; i += (int)blockDim.x)
+        if (cnt[i]) atomicAdd(&L.frame_counts[i], cnt[i]);
+#ifdef RT_COUNT
+    walk_count_flush(wc, 8);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The whole ray tree of a sample in one launch, for frames too small to fill the chip pass by pass.
 //
 // The wavefront pipeline above spends a launch per generation and kind of ray; a frame of a few hundred thousand

@@ -72,6 +72,7 @@ void *g_scratch_ptr[RT_MAX_DEVICES] = {};       // per device: address of that d
 #define RT_DEFAULT_QUEUE_BUDGET ((size_t)32 << 30)
 // Frames of at most this many samples run as one launch per batch (k_fused) instead of the wavefront pipeline.
 #define RT_FUSED_MAX_SAMPLES (1ll << 20)
+#define RT_LOCAL_MAX_SAMPLES (1ll << 22)     // frames up to this many samples run as one launch of self-contained blocks (k_local)
 
 // Experiment switches (rt_debug_set_option); the defaults are what the product runs.
 struct DebugOptions {
@@ -83,6 +84,8 @@ struct DebugOptions {
     int leaf_max = 0, split_budget = -1;   // hierarchy builder (accel::Options), read at the next upload
     int lightcam_host = 0;          // 1: the light cameras' point octrees are built by the host builder (lightcam_build.cpp)
     int fused = -1;                 // 1: always the one-launch kernel, 0: never, -1: by frame size
+    int local_threads = 1024;       // block size of the block-local kernel (256, 512 or 1024)
+    int local = -1;                 // 1: always the block-local one-launch kernel where it applies, 0: never, -1: by frame size
     int units = 1;                  // 0: the primary pass never shares its chunks out on the device (every block keeps to a fixed share)
     int overlap = -1;               // 1: shadow passes on the second stream beside the next closest-hit pass, 0: one stream, -1: by batch size
     int pair = -1;                  // 1: shadow pass g and closest-hit pass g+1 in one launch, 0: a launch each, -1: default (paired)
@@ -228,6 +231,7 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
                                  (const void *)k_shadow_hybrid,
                                  (const void *)k_pair<true, SHADOW_BVH>, (const void *)k_pair<true, SHADOW_HYBRID>,
                                  (const void *)k_pair<true, SHADOW_EXACT>, (const void *)k_pair<false, SHADOW_EXACT>,
+                                 (const void *)k_local<SHADOW_BVH>,
                                  (const void *)k_fused<true, SHADOW_BVH>, (const void *)k_fused<true, SHADOW_HYBRID>,
                                  (const void *)k_fused<true, SHADOW_EXACT>, (const void *)k_fused<false, SHADOW_EXACT>};
         for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
@@ -911,7 +915,7 @@ static void plan_queues(QueuePlan &q, long long batch_chunks, int waves_per_bloc
     // the shard given by its number, so a shard holds at most its share of the units whichever blocks worked on them.
     q.unit_chunks = 0;
     if (units_allowed && batch_chunks >= 16 * w0 && blocks0 == max_blocks) {
-        q.unit_chunks = 64;
+        q.unit_chunks = 32;      // 16 to 128 measure alike (8K teapot frame, 2 to 8 batches: within 0.5 %), 256 is 2-4 % slower
         const long long units = (batch_chunks + q.unit_chunks - 1) / q.unit_chunks;
         q.hit_cap[0] = ((units + N_SHARDS - 1) / N_SHARDS) * q.unit_chunks * 64;
     }
@@ -1108,10 +1112,15 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const bool use_fused = !noalloc && local_rows > 0 &&
                            (ctx->dbg.fused == 1 || (ctx->dbg.fused < 0 && (long long)n_pixels * spp <= RT_FUSED_MAX_SAMPLES &&
                                                     !ctx->any_secondary && !(o->flags & RT_FLAG_KEEP_ZERO_WEIGHT)));
-    int block = (noalloc || use_fused || batch_chunks * 64 <= (1ll << 22)) ? 256 : RT_BLOCK;
+    // The block-local one-launch kernel (k_local) takes frames of one batch that are too small to fill the chip pass by
+    // pass, in scenes whose trees go on after the first hit and whose shadow queries take the hierarchies.
+    const bool want_local = !noalloc && !use_fused && local_rows > 0 && may_cull && ctx->accel_usable && !ctx->any_transparent_sphere &&
+                            batch_chunks >= n_chunks &&
+                            (ctx->dbg.local == 1 || (ctx->dbg.local < 0 && n_chunks * 64 <= RT_LOCAL_MAX_SAMPLES));
+    int block = want_local ? ctx->dbg.local_threads : (noalloc || use_fused || batch_chunks * 64 <= (1ll << 22)) ? 256 : RT_BLOCK;
     if (!use_fused && (ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024)) block = ctx->dbg.block_threads;
     const int blocks_per_cu = 1024 / block, waves_per_block = block / 64;
-    P.S.stack_shift = block == 256 ? 8 : 10;
+    P.S.stack_shift = block == 256 ? 8 : (block == 512 ? 9 : 10);
     // LDS per block: the stacks, the material and light tables, then as many top-of-tree nodes as fit
     // beside them when the compute unit holds 1024 threads (the register budget allows four waves per SIMD).
     // A tree so deep that its stacks alone do not fit keeps to the octree walk.
@@ -1132,7 +1141,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const size_t lds_tables = (size_t)(P.S.mat_cached + P.S.light_cached) * 64;
     {
         const size_t per_block = lds_block;
-        const size_t fixed = lds_stack + lds_tables + 128 + 512;
+        const size_t fixed = lds_stack + lds_tables + 128 + 512 + (want_local ? CNT_WORDS * sizeof(uint32_t) : 0);
         long long room = per_block > fixed ? (long long)((per_block - fixed) / (NODE_LDS_WORDS * 4)) : 0;
         if (ctx->dbg.node_cache >= 0 && ctx->dbg.node_cache < room) room = ctx->dbg.node_cache;
         // the triangle hierarchy first, the sphere hierarchy takes what is left; split evenly when both are large
@@ -1161,6 +1170,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     // every traversal kernel gets the same layout (the octree-walk variants use the tables only)
     const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int) +
                            (size_t)P.S.btri_cached * 80 + lds_tables + 128 + 32;
+    const bool use_local = want_local && bvh_closest_ok && bvh_shadow_ok;
+    const int lds_counts_word = P.S.lds_ticket_word + 8;                 // k_local: the block's own queue counters
+    const size_t lds_local = lds_bvh + CNT_WORDS * sizeof(uint32_t);
     const size_t lds_closest = lds_bvh;
     const size_t lds_shadow = lds_bvh;
     const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
@@ -1184,6 +1196,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         return !noalloc && !use_fused && P.S.n_lights > 0 && (ctx->dbg.pair == 1 || (ctx->dbg.pair < 0 && chunks * 64 <= (1ll << 24)));
     };
     long long fused_defer_cap = 0;
+    LocalPlan LP{};
+    long long local_grid = 0;
     if (use_fused) {
         // no ray or hit queues; only the deferred light-camera queries leave the kernel (when that queue is full they are
         // answered in place, so its size is a matter of speed, not of correctness)
@@ -1199,6 +1213,30 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         }
         B.accum = ctx->accum;
         B.deferred[0] = ctx->deferred[0];
+        B.counts = ctx->counts;
+        B.totals = ctx->totals;
+        } else if (use_local) {
+        // one block per compute unit when the frame has that many runs of sixteen chunks; a block's queues hold what its
+        // own samples can spawn (with two rays per hit, `growth` times the first generation, as in plan_queues)
+        const long long slots = (long long)waves_per_block * ctx->cu_count * blocks_per_cu;     // resident waves
+        const long long k = (n_chunks + slots - 1) / slots;
+        const long long cpb = waves_per_block * k;
+        LP.chunks_per_block = (uint32_t)cpb;
+        local_grid = (n_chunks + cpb - 1) / cpb;
+        const long long cap = cpb * 64 * (fan_out > 1 ? (long long)ctx->growth : 1ll);
+        LP.ray_cap = LP.hit_cap = (uint32_t)cap;
+        const size_t hit_stride = all_flat ? 64 : sizeof(HitRec);
+        int rc;
+        if ((rc = ensure(&ctx->accum, &ctx->accum_values, n_pixels * 3)) != RT_OK) return rc;
+        for (int kk = 0; kk < 2; ++kk) {
+            if ((rc = ensure(&ctx->rays[kk], &ctx->ray_capacity[kk], (size_t)(local_grid * cap))) != RT_OK) return rc;
+            if ((rc = ensure(&ctx->hits[kk], &ctx->hit_capacity[kk], ((size_t)(local_grid * cap) * hit_stride + sizeof(HitRec) - 1) / sizeof(HitRec))) != RT_OK) return rc;
+            LP.rays[kk] = ctx->rays[kk];
+            LP.hits[kk] = ctx->hits[kk];
+        }
+        LP.lds_counts_word = lds_counts_word;
+        LP.frame_counts = ctx->counts;
+        B.accum = ctx->accum;
         B.counts = ctx->counts;
         B.totals = ctx->totals;
         } else if (local_rows > 0 && !noalloc) {
@@ -1293,7 +1331,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     ctx->pending_batches = 0;
     ctx->pending_primaries = (unsigned long long)n_pixels * (unsigned long long)(N * N);
     ctx->pending_totals = B.totals;
-    ctx->pending_fused = use_fused;
+    ctx->pending_fused = use_fused || use_local;
 
     if (local_rows > 0) {
         HIP_TRY(hipMemsetAsync(B.accum, 0, n_pixels * 3 * sizeof(double), st));
@@ -1376,6 +1414,25 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, counts, B.totals, P.S.n_lights);
                 ctx->pending_batches++;
             }
+            HIP_TRY(hipEventRecord(ctx->ev_batch[0], st));
+        } else if (use_local) {
+            uint32_t *counts = B.counts;
+            HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
+            QueueSet Q{};
+            Q.counts = counts;
+            Q.hit_stride = all_flat ? 64u : 128u;
+            Q.chunk_begin = 0;
+            Q.chunk_end = n_chunks;
+            Q.block_row0 = 0;
+            Q.block_col0 = 0;
+            std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+            if (timing && !(ev = next_event_pair(ctx->ev_closest, ctx->ev_closest_used))) return fail(RT_ERR_DEVICE, "hipEventCreate failed");
+            if (ev) HIP_TRY(hipEventRecord(ev->first, st));
+            hipLaunchKernelGGL((k_local<SHADOW_BVH>), dim3((unsigned)local_grid), dim3(block), lds_local, st, P, Q, LP);
+            if (ev) HIP_TRY(hipEventRecord(ev->second, st));
+            hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, counts, B.totals, P.S.n_lights);
+            ctx->pending_batches++;
+            batch_no = 1;
             HIP_TRY(hipEventRecord(ctx->ev_batch[0], st));
         } else
         for (long long t0 = 0; t0 < n_chunks; t0 += batch_chunks, ++batch_no) {
@@ -1531,7 +1588,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         }
         // the frame is complete when the second stream has drained
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[0], 0));
-        if (batch_no >= 2 && !use_fused) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[1], 0));
+        if (batch_no >= 2 && !use_fused && !use_local) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[1], 0));
         HIP_TRY(hipGetLastError());
         {
             const long long n_values = (long long)n_pixels * 3;
@@ -1677,6 +1734,8 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "lightcam_host") { ctx->dbg.lightcam_host = (int)value; free_lightcams(ctx); }
     else if (n == "fused") ctx->dbg.fused = (int)value;
     else if (n == "units") ctx->dbg.units = (int)value;
+    else if (n == "local") ctx->dbg.local = (int)value;
+    else if (n == "local_threads") ctx->dbg.local_threads = (value == 256 || value == 512) ? (int)value : 1024;
     else if (n == "overlap") ctx->dbg.overlap = (int)value;
     else if (n == "pair") ctx->dbg.pair = (int)value;
     else if (n == "queue_growth") ctx->growth = value < 1 ? 1 : (value > 32 ? 32 : (int)value);

@@ -276,6 +276,34 @@ def test_paired_and_separate_passes_agree(gpu, oracle_frame, scene, res):
         assert np.array_equal(g["lightcam_mask"], o["lightcam_mask"])
 
 
+@pytest.mark.parametrize("scene,res", [("teapot-3", None), ("balls", (256, 256)), ("refract", (320, 200)), ("gears", (192, 192)),
+                                       ("teapot-3", (1200, 1000))])
+def test_self_contained_blocks_agree_with_the_passes(gpu, oracle_frame, scene, res):
+    """Small frames of scenes whose shadow queries take the hierarchies run as one launch of blocks that each carry
+    their own samples through all generations (queues and counters of their own); the launch-per-pass pipeline renders
+    the same frame with the same ray counts, and both match the oracle.  The last case has several runs of chunks per
+    block."""
+    s = load_scene(gpu, scene)
+    cam = s.camera(*res) if res else s.camera()
+    frames = []
+    for local in (1, 0):
+        gpu.set_option("local", local)
+        gpu.set_option("fused", 0)
+        try:
+            frames.append(gpu.render(cam, flags=rt.FLAG_KEEP_ZERO_WEIGHT))
+        finally:
+            gpu.set_option("local", -1)
+            gpu.set_option("fused", -1)
+    o = oracle_frame(scene, res=res)
+    for g in frames:
+        assert_frames_match(g, o, tol=1e-6)
+        assert g["stats"]["closest_rays"] == o["counters"]["closest_rays"]
+        assert g["stats"]["shadow_rays"] == o["counters"]["shadow_rays"]
+        assert g["stats"]["queue_overflow"] == 0
+    assert frames[0]["stats"]["rays_per_generation"] == frames[1]["stats"]["rays_per_generation"]
+    assert frames[0]["stats"]["hits_per_generation"] == frames[1]["stats"]["hits_per_generation"]
+
+
 def test_primary_pass_in_units_drawn_while_it_runs(gpu, oracle_frame):
     """A primary pass with many chunks per wave hands its chunks out in units while it runs (a counter in memory, a
     permuted order, records sharded by unit) instead of giving every block a fixed share: the same frame and ray counts
