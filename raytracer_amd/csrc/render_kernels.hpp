@@ -521,10 +521,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_pair(FramePar
 // frame's sharded queues).
 struct LocalPlan {
     uint32_t chunks_per_block;   // primary chunks of a block
-    uint32_t ray_cap, hit_cap;   // records of one block in one ray buffer / the hit buffer of one parity
-    int32_t lds_counts_word;     // first LDS word of the block's CNT_WORDS counters
+    uint32_t ray_cap, hit_cap;   // records of one block in one ray buffer / in the hit buffer of one generation
+    int32_t lds_counts_word;     // first LDS word of the block's CNT_WORDS counters, followed by 32 words of bookkeeping
     RayRec *rays[2];             // by generation parity
-    HitRec *hits[2];
+    HitRec *hits;                // one slice per generation and block
     uint32_t *frame_counts;      // the frame's counters
 };
 template <int MODE>
@@ -538,9 +538,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
     if ((long long)blockIdx.x >= n_chunks) return;
     const uint32_t my_chunks = (uint32_t)((n_chunks - blockIdx.x + gridDim.x - 1) / gridDim.x);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(&s_lds[L.lds_counts_word]);
-    for (int i = (int)threadIdx.x; i < CNT_WORDS; i += (int)blockDim.x) cnt[i] = 0u;
+    for (int i = (int)threadIdx.x; i < CNT_WORDS + 32; i += (int)blockDim.x) cnt[i] = 0u;
     if (threadIdx.x == 0) camera_to_lds(P);
-    fill_node_cache(P.S, true);      // ends with the block's barrier, ticket at zero
+    fill_node_cache(P.S, true);      // ends with the block's barrier
     const bool cull_s = P.cull_shadow != 0, cull_c = P.cull_closest != 0;
     const uint32_t nl = (uint32_t)P.S.n_lights;
     const size_t hit_bytes = (size_t)L.hit_cap * Q0.hit_stride;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
         QueueSet Q = Q0;
         Q.rays_in = L.rays[g & 1] + (size_t)blockIdx.x * L.ray_cap;
         Q.rays_out = L.rays[(g + 1) & 1] + (size_t)blockIdx.x * L.ray_cap;
-        Q.hits = reinterpret_cast<HitRec *>(reinterpret_cast<char *>(L.hits[g & 1]) + (size_t)blockIdx.x * hit_bytes);
+        Q.hits = reinterpret_cast<HitRec *>(reinterpret_cast<char *>(L.hits) + ((size_t)g * gridDim.x + blockIdx.x) * hit_bytes);
         Q.counts = cnt;
         Q.in_shard_cap = L.ray_cap;
         Q.out_shard_cap = g < 5 ? L.ray_cap : 0u;
@@ -566,36 +566,67 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
         m.total = (n * per_record + 63u) >> 6;
         return m;
     };
-    // primary pass
-    {
-        const QueueSet Qc = queue_set(0);
-        ShardMap none;
-        none.items = none.first = none.total = 0u;
-        for (;;) {
-            int t = 0;
-            if (lane == 0) t = atomicAdd(&s_lds[P.S.lds_ticket_word], 1);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if ((uint32_t)t >= my_chunks) break;
-            closest_chunk<true, true>(P, Qc, none, (long long)blockIdx.x + (long long)t * gridDim.x, lane, stack, cull_c, wc, 0u);
+    // No barrier between the passes: the closest-hit passes C_0 .. C_5 are the only chain of dependences (C_g+1 traces
+    // what C_g spawned), the shadow pass of a generation can run any time after that generation's closest-hit pass.  Each
+    // wave keeps its own position: it takes a closest-hit chunk of the generation it is at while there is one, else a
+    // shadow chunk of any generation already complete, else it waits until the last closest-hit chunks of its
+    // generation are done (counted in LDS after a fence) and moves to the next.  Waves that find nothing to trace shade,
+    // so the chain of six closest-hit rounds is all that is ever waited for.
+    volatile uint32_t *sync = reinterpret_cast<volatile uint32_t *>(&s_lds[L.lds_counts_word + CNT_WORDS]);   // taken_c[6], done_c[6], taken_s[6]
+    uint32_t *sync_rw = const_cast<uint32_t *>(sync);
+    auto take = [&](int word, uint32_t total) {       // a ticket below `total`, or ~0u
+        uint32_t t = ~0u;
+        if (sync[word] < total) {
+            if (lane == 0) t = atomicAdd(&sync_rw[word], 1u);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            if (t >= total) t = ~0u;
         }
-    }
-    // S_g + C_g+1 for g = 0..4, then S_5
-    for (int g = 0; g < 6; ++g) {
-        __syncthreads();
-        if (threadIdx.x == 0) s_lds[P.S.lds_ticket_word] = 0;
-        __syncthreads();
-        const QueueSet Qs = queue_set(g), Qc = queue_set(g < 5 ? g + 1 : 5);
-        const ShardMap sm_s = local_map(nl ? cnt[CNT_HITS(g)] : 0u, L.hit_cap, nl);
-        const ShardMap sm_c = local_map(g < 5 ? cnt[CNT_RAYS(g + 1)] : 0u, L.ray_cap, 1u);
-        const uint32_t n_s = sm_s.total, total = n_s + sm_c.total;
-        if (total == 0) break;           // the same for every thread of the block: nothing left in this block's trees
-        for (;;) {
-            int t = 0;
-            if (lane == 0) t = atomicAdd(&s_lds[P.S.lds_ticket_word], 1);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if ((uint32_t)t >= total) break;
-            if ((uint32_t)t < n_s) shadow_chunk<MODE>(P, Qs, sm_s, nl, (long long)t, stack, cull_s, wc);
-            else closest_chunk<false, true>(P, Qc, sm_c, (long long)((uint32_t)t - n_s), lane, stack, cull_c, wc, 0u);
+        return t;
+    };
+    ShardMap none;
+    none.items = none.first = none.total = 0u;
+    int g = 0;
+    uint32_t total_c = my_chunks;
+    uint32_t spins = 0;
+    for (;;) {
+        if (g < 6) {
+            const uint32_t t = take(g, total_c);
+            if (t != ~0u) {
+                const QueueSet Qc = queue_set(g);
+                if (g == 0) closest_chunk<true, true>(P, Qc, none, (long long)blockIdx.x + (long long)t * gridDim.x, lane, stack, cull_c, wc, 0u);
+                else closest_chunk<false, true>(P, Qc, local_map(cnt[CNT_RAYS(g)], L.ray_cap, 1u), (long long)t, lane, stack, cull_c, wc, 0u);
+                __threadfence_block();            // the records are written before the chunk counts as done
+                if (lane == 0) atomicAdd(&sync_rw[6 + g], 1u);
+                spins = 0;
+                continue;
+            }
+        }
+        bool shaded = false;
+        for (int gg = 0; gg < g && !shaded; ++gg) {
+            const ShardMap sm_s = local_map(nl ? cnt[CNT_HITS(gg)] : 0u, L.hit_cap, nl);
+            const uint32_t t = take(12 + gg, sm_s.total);
+            if (t != ~0u) {
+                const QueueSet Qs = queue_set(gg);
+                shadow_chunk<MODE>(P, Qs, sm_s, nl, (long long)t, stack, cull_s, wc);
+                shaded = true;
+            }
+        }
+        if (shaded) { spins = 0; continue; }
+        if (g == 6) break;                        // every generation is traced and no shadow chunk is left to take
+        if (sync[6 + g] == total_c) {
+            __threadfence_block();                // generation g is complete: what it wrote may be read
+            ++g;
+            total_c = 0u;
+            if (g < 6) {
+                const uint32_t n = cnt[CNT_RAYS(g)];
+                total_c = ((n < L.ray_cap ? n : L.ray_cap) + 63u) >> 6;
+            }
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) {               // cannot happen (a chunk taken is a chunk finished); reported, not waited out
+            cnt[CNT_OVERFLOW] = 1u;
+            break;
         }
     }
     __syncthreads();
@@ -1027,12 +1058,13 @@ __global__ void k_collect_counts(const uint32_t *counts, unsigned long long *tot
     if (lane == 0) totals[15] += counts[CNT_OVERFLOW];
 }
 
-__global__ __launch_bounds__(256) void k_finalize(const double *accum, long long n_values, int spp, double *out_f64,
-                                                  uint8_t *out_u8)
+// (the accumulation frame is left at zero: the next frame of the context starts from it)
+__global__ __launch_bounds__(256) void k_finalize(double *accum, long long n_values, int spp, double *out_f64, uint8_t *out_u8)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride) {
         double c = accum[i] / (double)spp;
+        accum[i] = 0.0;
         c = (c < 1.0) ? c : 1.0;        // std::min(1.0, c)
         c = (0.0 < c) ? c : 0.0;        // std::max(0.0, c)
         double v = c * 255;

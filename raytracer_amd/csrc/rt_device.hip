@@ -72,7 +72,7 @@ void *g_scratch_ptr[RT_MAX_DEVICES] = {};       // per device: address of that d
 #define RT_DEFAULT_QUEUE_BUDGET ((size_t)32 << 30)
 // Frames of at most this many samples run as one launch per batch (k_fused) instead of the wavefront pipeline.
 #define RT_FUSED_MAX_SAMPLES (1ll << 20)
-#define RT_LOCAL_MAX_SAMPLES (1ll << 22)     // frames up to this many samples run as one launch of self-contained blocks (k_local)
+#define RT_LOCAL_MAX_SAMPLES (1ll << 19)     // frames up to this many samples run as one launch of self-contained blocks (k_local)
 
 // Experiment switches (rt_debug_set_option); the defaults are what the product runs.
 struct DebugOptions {
@@ -132,6 +132,9 @@ struct rt_ctx {
     hipEvent_t ev_c[6] = {}, ev_s[6] = {}, ev_batch[2] = {};
     uint32_t *counts = nullptr;
     unsigned long long *totals = nullptr;
+    unsigned long long *h_totals = nullptr;     // pinned: the totals of the frame in flight arrive here with the frame's last command
+    const double *accum_clean_ptr = nullptr;
+    size_t accum_clean = 0;                     // leading values of `accum` known to be zero (k_finalize leaves them so)
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr}; size_t stage_bytes[4] = {0, 0, 0, 0};
     int64_t batch_override = 0;
     size_t queue_budget = RT_DEFAULT_QUEUE_BUDGET;
@@ -221,8 +224,11 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
     for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_batch[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&ctx->ev_begin));
     HIP_TRY(hipEventCreate(&ctx->ev_end));
-    HIP_TRY(hipMalloc((void **)&ctx->counts, 2 * CNT_WORDS * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&ctx->totals, RT_TOTALS_WORDS * sizeof(unsigned long long)));
+    // the frame's totals, then the two counter blocks, in one allocation: a frame's first memset clears the totals and
+    // the first batch's counters together
+    HIP_TRY(hipMalloc((void **)&ctx->totals, RT_TOTALS_WORDS * sizeof(unsigned long long) + 2 * CNT_WORDS * sizeof(uint32_t)));
+    ctx->counts = reinterpret_cast<uint32_t *>(ctx->totals + RT_TOTALS_WORDS);
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_totals, RT_TOTALS_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     {
         // a block of the traversal kernels may use all of a compute unit's LDS
         const int lds_max = (int)ctx->lds_per_cu;
@@ -266,8 +272,8 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ctx->ev_batch[k]);
     (void)hipStreamDestroy(ctx->stream2);
 
-    (void)hipFree(ctx->counts);
-    (void)hipFree(ctx->totals);
+    (void)hipFree(ctx->totals);      // (the counters are part of it)
+    (void)hipHostFree(ctx->h_totals);
     (void)hipFree(ctx->lc_ws);
     (void)hipFree(ctx->lc_photon_ws);
     (void)hipFree(ctx->lc_packed);
@@ -1141,7 +1147,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const size_t lds_tables = (size_t)(P.S.mat_cached + P.S.light_cached) * 64;
     {
         const size_t per_block = lds_block;
-        const size_t fixed = lds_stack + lds_tables + 128 + 512 + (want_local ? CNT_WORDS * sizeof(uint32_t) : 0);
+        const size_t fixed = lds_stack + lds_tables + 128 + 512 + (want_local ? (CNT_WORDS + 32) * sizeof(uint32_t) : 0);
         long long room = per_block > fixed ? (long long)((per_block - fixed) / (NODE_LDS_WORDS * 4)) : 0;
         if (ctx->dbg.node_cache >= 0 && ctx->dbg.node_cache < room) room = ctx->dbg.node_cache;
         // the triangle hierarchy first, the sphere hierarchy takes what is left; split evenly when both are large
@@ -1170,9 +1176,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     // every traversal kernel gets the same layout (the octree-walk variants use the tables only)
     const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int) +
                            (size_t)P.S.btri_cached * 80 + lds_tables + 128 + 32;
-    const bool use_local = want_local && bvh_closest_ok && bvh_shadow_ok;
+    bool use_local = want_local && bvh_closest_ok && bvh_shadow_ok;      // (and its queues within the memory budget, below)
     const int lds_counts_word = P.S.lds_ticket_word + 8;                 // k_local: the block's own queue counters
-    const size_t lds_local = lds_bvh + CNT_WORDS * sizeof(uint32_t);
+    const size_t lds_local = lds_bvh + (CNT_WORDS + 32) * sizeof(uint32_t);
     const size_t lds_closest = lds_bvh;
     const size_t lds_shadow = lds_bvh;
     const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
@@ -1197,7 +1203,19 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     };
     long long fused_defer_cap = 0;
     LocalPlan LP{};
-    long long local_grid = 0;
+    long long local_grid = 0, local_cap = 0;
+    if (use_local) {
+        // one block per compute unit when the frame has that many runs of sixteen chunks; a block's queues hold what its
+        // own samples can spawn (with two rays per hit, `growth` times the first generation, as in plan_queues)
+        const long long slots = (long long)waves_per_block * ctx->cu_count * blocks_per_cu;     // resident waves
+        const long long k = (n_chunks + slots - 1) / slots;
+        const long long cpb = waves_per_block * k;
+        LP.chunks_per_block = (uint32_t)cpb;
+        local_grid = (n_chunks + cpb - 1) / cpb;
+        local_cap = cpb * 64 * (fan_out > 1 ? (long long)ctx->growth : 1ll);
+        const size_t bytes = (size_t)(local_grid * local_cap) * (2 * sizeof(RayRec) + 6 * (all_flat ? 64 : sizeof(HitRec)));
+        if (bytes > ctx->queue_budget) use_local = false;        // the launch-per-pass path cuts the frame into batches
+    }
     if (use_fused) {
         // no ray or hit queues; only the deferred light-camera queries leave the kernel (when that queue is full they are
         // answered in place, so its size is a matter of speed, not of correctness)
@@ -1216,24 +1234,19 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         B.counts = ctx->counts;
         B.totals = ctx->totals;
         } else if (use_local) {
-        // one block per compute unit when the frame has that many runs of sixteen chunks; a block's queues hold what its
-        // own samples can spawn (with two rays per hit, `growth` times the first generation, as in plan_queues)
-        const long long slots = (long long)waves_per_block * ctx->cu_count * blocks_per_cu;     // resident waves
-        const long long k = (n_chunks + slots - 1) / slots;
-        const long long cpb = waves_per_block * k;
-        LP.chunks_per_block = (uint32_t)cpb;
-        local_grid = (n_chunks + cpb - 1) / cpb;
-        const long long cap = cpb * 64 * (fan_out > 1 ? (long long)ctx->growth : 1ll);
+        const long long cap = local_cap;
         LP.ray_cap = LP.hit_cap = (uint32_t)cap;
         const size_t hit_stride = all_flat ? 64 : sizeof(HitRec);
         int rc;
         if ((rc = ensure(&ctx->accum, &ctx->accum_values, n_pixels * 3)) != RT_OK) return rc;
         for (int kk = 0; kk < 2; ++kk) {
             if ((rc = ensure(&ctx->rays[kk], &ctx->ray_capacity[kk], (size_t)(local_grid * cap))) != RT_OK) return rc;
-            if ((rc = ensure(&ctx->hits[kk], &ctx->hit_capacity[kk], ((size_t)(local_grid * cap) * hit_stride + sizeof(HitRec) - 1) / sizeof(HitRec))) != RT_OK) return rc;
             LP.rays[kk] = ctx->rays[kk];
-            LP.hits[kk] = ctx->hits[kk];
         }
+        // a hit slice per generation: shadow chunks are taken whenever a wave has nothing to trace, so a generation's hits
+        // may still be waiting when the generation after the next is being traced
+        if ((rc = ensure(&ctx->hits[0], &ctx->hit_capacity[0], ((size_t)(6 * local_grid * cap) * hit_stride + sizeof(HitRec) - 1) / sizeof(HitRec))) != RT_OK) return rc;
+        LP.hits = ctx->hits[0];
         LP.lds_counts_word = lds_counts_word;
         LP.frame_counts = ctx->counts;
         B.accum = ctx->accum;
@@ -1324,7 +1337,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
 
     hipStream_t st = ctx->stream;
     HIP_TRY(hipEventRecord(ctx->ev_begin, st));
-    HIP_TRY(hipMemsetAsync(B.totals, 0, RT_TOTALS_WORDS * sizeof(unsigned long long), st));
+    // (the first batch's counter block lies right behind the context's totals: one memset for both)
+    const bool counts0_clear = !noalloc && local_rows > 0 && B.totals == ctx->totals && B.counts == ctx->counts;
+    HIP_TRY(hipMemsetAsync(B.totals, 0, RT_TOTALS_WORDS * sizeof(unsigned long long) + (counts0_clear ? CNT_WORDS * sizeof(uint32_t) : 0), st));
     ctx->ev_closest_used = ctx->ev_shadow_used = ctx->ev_pair_used = 0;
     ctx->pending_closest_per_batch = use_pair ? 1 : 6;
     ctx->pending_flags = o->flags;
@@ -1334,7 +1349,11 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     ctx->pending_fused = use_fused || use_local;
 
     if (local_rows > 0) {
-        HIP_TRY(hipMemsetAsync(B.accum, 0, n_pixels * 3 * sizeof(double), st));
+        // k_finalize leaves the values it has read at zero, so only a frame that finds the buffer new, larger than the last
+        // frame's or left behind by a failed call clears it first
+        if (!(B.accum == ctx->accum && ctx->accum_clean_ptr == ctx->accum && ctx->accum_clean >= n_pixels * 3))
+            HIP_TRY(hipMemsetAsync(B.accum, 0, n_pixels * 3 * sizeof(double), st));
+        ctx->accum_clean = 0;
         P.accum = B.accum;
 
         // outputs: device pointers are used directly, host pointers go through staging buffers
@@ -1378,7 +1397,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             for (long long t0 = 0; t0 < n_chunks; t0 += batch_chunks, ++batch_no) {
                 const long long t1 = (t0 + batch_chunks < n_chunks) ? t0 + batch_chunks : n_chunks;
                 uint32_t *counts = B.counts;
-                HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
+                if (!(batch_no == 0 && counts0_clear)) HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
                 QueueSet Q{};
                 Q.deferred = B.deferred[0];
                 Q.counts = counts;
@@ -1417,7 +1436,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             HIP_TRY(hipEventRecord(ctx->ev_batch[0], st));
         } else if (use_local) {
             uint32_t *counts = B.counts;
-            HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
+            if (!counts0_clear) HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
             QueueSet Q{};
             Q.counts = counts;
             Q.hit_stride = all_flat ? 64u : 128u;
@@ -1440,7 +1459,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             const int par = (int)(batch_no & 1);
             uint32_t *counts = B.counts + (size_t)par * CNT_WORDS;
             if (batch_no >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[par], 0));
-            HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
+            if (!(batch_no == 0 && counts0_clear)) HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
             auto queue_set = [&](int g) {
                 QueueSet Q{};
                 Q.rays_in = B.rays[g & 1];
@@ -1597,11 +1616,13 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             hipLaunchKernelGGL(k_finalize, dim3((unsigned)blocks), dim3(256), 0, st, B.accum, n_values, N * N,
                                static_cast<double *>(dev[0]), static_cast<uint8_t *>(dev[1]));
             HIP_TRY(hipGetLastError());
+            if (B.accum == ctx->accum) { ctx->accum_clean = (size_t)n_values; ctx->accum_clean_ptr = ctx->accum; }
         }
         if (!outputs_on_device)
             for (int k = 0; k < 4; ++k)
                 if (dst[k]) HIP_TRY(hipMemcpyAsync(dst[k], dev[k], bytes[k], hipMemcpyDeviceToHost, st));
     }
+    HIP_TRY(hipMemcpyAsync(ctx->h_totals, B.totals, RT_TOTALS_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(ctx->ev_end, st));
     ctx->pending = true;
     return RT_OK;
@@ -1615,7 +1636,7 @@ extern "C" int rt_sync(rt_ctx *ctx, rt_stats *stats)
     ctx->pending = false;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     unsigned long long tot[RT_TOTALS_WORDS];
-    HIP_TRY(hipMemcpy(tot, ctx->pending_totals, sizeof tot, hipMemcpyDeviceToHost));
+    std::memcpy(tot, ctx->h_totals, sizeof tot);      // copied by the frame's last command
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         tot[0] += ctx->pending_primaries;   // generation 0 is counted on the host
