@@ -237,6 +237,20 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
                               rec_pack_words(pixel, (uint32_t)(L - 1), 0u, 0u)};
         rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_b], q);
     }
+    if (Q.commit && n_a + n_b) {
+        // (k_local) the rays are written: count them into the 64-record pieces of the list they lie in, so that a piece
+        // that is full can be traced before the rest of this generation is done
+        __threadfence_block();
+        if (lane == 0) {
+            uint32_t s0 = base_r, e0 = base_r + n_a + n_b;
+            if (e0 > Q.out_shard_cap) e0 = Q.out_shard_cap;
+            while (s0 < e0) {
+                const uint32_t ce = (s0 | 63u) + 1u < e0 ? (s0 | 63u) + 1u : e0;
+                atomicAdd(&Q.commit[s0 >> 6], ce - s0);
+                s0 = ce;
+            }
+        }
+    }
     STAMP(8);
 
 #undef STAMP_SEL
@@ -521,9 +535,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_pair(FramePar
 // frame's sharded queues).
 struct LocalPlan {
     uint32_t chunks_per_block;   // primary chunks of a block
-    uint32_t ray_cap, hit_cap;   // records of one block in one ray buffer / in the hit buffer of one generation
-    int32_t lds_counts_word;     // first LDS word of the block's CNT_WORDS counters, followed by 32 words of bookkeeping
-    RayRec *rays[2];             // by generation parity
+    uint32_t ray_cap, hit_cap;   // records of one block's ray list / hit list of one generation
+    int32_t lds_counts_word;     // first LDS word of the block's CNT_WORDS counters, followed by 32 words of bookkeeping and a word
+                                 // per 64 records of the ray lists of generations 1..5
+    RayRec *rays;                // one slice per generation (1..6) and block
     HitRec *hits;                // one slice per generation and block
     uint32_t *frame_counts;      // the frame's counters
 };
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
     if ((long long)blockIdx.x >= n_chunks) return;
     const uint32_t my_chunks = (uint32_t)((n_chunks - blockIdx.x + gridDim.x - 1) / gridDim.x);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(&s_lds[L.lds_counts_word]);
-    for (int i = (int)threadIdx.x; i < CNT_WORDS + 32; i += (int)blockDim.x) cnt[i] = 0u;
+    for (int i = (int)threadIdx.x; i < CNT_WORDS + 32 + 5 * (int)(L.ray_cap >> 6); i += (int)blockDim.x) cnt[i] = 0u;
     if (threadIdx.x == 0) camera_to_lds(P);
     fill_node_cache(P.S, true);      // ends with the block's barrier
     const bool cull_s = P.cull_shadow != 0, cull_c = P.cull_closest != 0;
@@ -547,8 +562,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
     WalkCount wc{};
     auto queue_set = [&](int g) {
         QueueSet Q = Q0;
-        Q.rays_in = L.rays[g & 1] + (size_t)blockIdx.x * L.ray_cap;
-        Q.rays_out = L.rays[(g + 1) & 1] + (size_t)blockIdx.x * L.ray_cap;
+        // (a slice per generation, not two in turn: the first chunks of generation g+1 write the rays of generation g+2
+        // while the last chunks of generation g still read theirs)
+        Q.rays_in = L.rays + ((size_t)g * gridDim.x + blockIdx.x) * L.ray_cap;
+        Q.rays_out = L.rays + ((size_t)(g + 1) * gridDim.x + blockIdx.x) * L.ray_cap;
         Q.hits = reinterpret_cast<HitRec *>(reinterpret_cast<char *>(L.hits) + ((size_t)g * gridDim.x + blockIdx.x) * hit_bytes);
         Q.counts = cnt;
         Q.in_shard_cap = L.ray_cap;
@@ -566,14 +583,18 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
         m.total = (n * per_record + 63u) >> 6;
         return m;
     };
-    // No barrier between the passes: the closest-hit passes C_0 .. C_5 are the only chain of dependences (C_g+1 traces
-    // what C_g spawned), the shadow pass of a generation can run any time after that generation's closest-hit pass.  Each
-    // wave keeps its own position: it takes a closest-hit chunk of the generation it is at while there is one, else a
-    // shadow chunk of any generation already complete, else it waits until the last closest-hit chunks of its
-    // generation are done (counted in LDS after a fence) and moves to the next.  Waves that find nothing to trace shade,
-    // so the chain of six closest-hit rounds is all that is ever waited for.
+    // No barrier between the passes.  The closest-hit passes C_0 .. C_5 are the only chain of dependences (C_g+1 traces
+    // what C_g spawned); the shadow pass of a generation can run any time after that generation's closest-hit pass.  Each
+    // wave keeps its own view of how far the block is (generations below `gd` are complete) and looks for work in this
+    // order: a closest-hit chunk of generation gd (its ray list is final); a closest-hit chunk of a later generation whose
+    // 64 rays have all been written already (the writers count them per 64-record piece, closest_chunk) -- so the
+    // stragglers of one generation run beside the first chunks of the next; a shadow chunk of any complete generation;
+    // else it waits until generation gd's last chunks are done (counted in LDS after a fence) and moves on.  A chunk is
+    // only ever taken when everything it reads is written, so a wave that holds work never waits for another.
+    const uint32_t pieces = L.ray_cap >> 6;       // 64-record pieces of a ray list
     volatile uint32_t *sync = reinterpret_cast<volatile uint32_t *>(&s_lds[L.lds_counts_word + CNT_WORDS]);   // taken_c[6], done_c[6], taken_s[6]
     uint32_t *sync_rw = const_cast<uint32_t *>(sync);
+    volatile uint32_t *written = sync + 32;       // [generation - 1][piece], generations 1..5
     auto take = [&](int word, uint32_t total) {       // a ticket below `total`, or ~0u
         uint32_t t = ~0u;
         if (sync[word] < total) {
@@ -585,24 +606,44 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
     };
     ShardMap none;
     none.items = none.first = none.total = 0u;
-    int g = 0;
+    int gd = 0;
     uint32_t total_c = my_chunks;
     uint32_t spins = 0;
     for (;;) {
-        if (g < 6) {
-            const uint32_t t = take(g, total_c);
+        int cg = -1;                // a closest-hit chunk to trace: generation, chunk, records its list is known to hold
+        uint32_t ct = 0, cn = 0;
+        bool retry = false;
+        if (gd < 6) {
+            const uint32_t t = take(gd, total_c);
             if (t != ~0u) {
-                const QueueSet Qc = queue_set(g);
-                if (g == 0) closest_chunk<true, true>(P, Qc, none, (long long)blockIdx.x + (long long)t * gridDim.x, lane, stack, cull_c, wc, 0u);
-                else closest_chunk<false, true>(P, Qc, local_map(cnt[CNT_RAYS(g)], L.ray_cap, 1u), (long long)t, lane, stack, cull_c, wc, 0u);
-                __threadfence_block();            // the records are written before the chunk counts as done
-                if (lane == 0) atomicAdd(&sync_rw[6 + g], 1u);
-                spins = 0;
-                continue;
+                cg = gd; ct = t;
+                cn = gd ? cnt[CNT_RAYS(gd)] : 0u;
+            }
+            for (int gg = gd + 1; gg < 6 && cg < 0 && !retry; ++gg) {
+                const uint32_t t2 = sync[gg];
+                if (t2 < pieces && written[(gg - 1) * pieces + t2] == 64u) {
+                    int won = 0;
+                    if (lane == 0) won = atomicCAS(&sync_rw[gg], t2, t2 + 1u) == t2 ? 1 : 0;
+                    won = __builtin_amdgcn_readfirstlane(won);
+                    if (won) { cg = gg; ct = t2; cn = (t2 + 1u) << 6; }
+                    else retry = true;            // another wave took it: look again
+                }
             }
         }
+        if (cg >= 0) {
+            __threadfence_block();                // what the chunk reads was written before it was announced
+            QueueSet Qc = queue_set(cg);
+            Qc.commit = cg < 5 ? const_cast<uint32_t *>(written) + cg * pieces : nullptr;
+            if (cg == 0) closest_chunk<true, true>(P, Qc, none, (long long)blockIdx.x + (long long)ct * gridDim.x, lane, stack, cull_c, wc, 0u);
+            else closest_chunk<false, true>(P, Qc, local_map(cn, L.ray_cap, 1u), (long long)ct, lane, stack, cull_c, wc, 0u);
+            __threadfence_block();                // the records are written before the chunk counts as done
+            if (lane == 0) atomicAdd(&sync_rw[6 + cg], 1u);
+            spins = 0;
+            continue;
+        }
+        if (retry) continue;
         bool shaded = false;
-        for (int gg = 0; gg < g && !shaded; ++gg) {
+        for (int gg = 0; gg < gd && !shaded; ++gg) {
             const ShardMap sm_s = local_map(nl ? cnt[CNT_HITS(gg)] : 0u, L.hit_cap, nl);
             const uint32_t t = take(12 + gg, sm_s.total);
             if (t != ~0u) {
@@ -612,13 +653,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
             }
         }
         if (shaded) { spins = 0; continue; }
-        if (g == 6) break;                        // every generation is traced and no shadow chunk is left to take
-        if (sync[6 + g] == total_c) {
-            __threadfence_block();                // generation g is complete: what it wrote may be read
-            ++g;
+        if (gd == 6) break;                       // every generation is traced and no shadow chunk is left to take
+        if (sync[6 + gd] == total_c) {
+            __threadfence_block();                // generation gd is complete: what it wrote may be read
+            ++gd;
             total_c = 0u;
-            if (g < 6) {
-                const uint32_t n = cnt[CNT_RAYS(g)];
+            if (gd < 6) {
+                const uint32_t n = cnt[CNT_RAYS(gd)];
                 total_c = ((n < L.ray_cap ? n : L.ray_cap) + 63u) >> 6;
             }
             continue;
@@ -1036,10 +1077,10 @@ __global__ __launch_bounds__(256) void k_pack_photons(const lightcam::Point *slo
     for (int k = 0; k < n; ++k) out[offsets[i] + k] = slots[(size_t)i * slots_per_ray + k];
 }
 
-__global__ void k_collect_counts(const uint32_t *counts, unsigned long long *totals, int n_lights)
+// One wave, lane = shard: a batch's queue counters added to the frame's totals.
+DEV void collect_counts(const uint32_t *counts, unsigned long long *totals, int n_lights)
 {
-    const int lane = (int)threadIdx.x;   // one wave, lane = shard
-    if (blockIdx.x != 0 || lane >= N_SHARDS) return;
+    const int lane = (int)threadIdx.x;
     for (int g = 0; g < 6; ++g) {
         unsigned long long r = (g == 0) ? 0ull : counts[CNT_RAYS(g) + lane];
         unsigned long long h = counts[CNT_HITS(g) + lane];
@@ -1057,10 +1098,24 @@ __global__ void k_collect_counts(const uint32_t *counts, unsigned long long *tot
     }
     if (lane == 0) totals[15] += counts[CNT_OVERFLOW];
 }
+__global__ void k_collect_counts(const uint32_t *counts, unsigned long long *totals, int n_lights)
+{
+    if (blockIdx.x != 0 || threadIdx.x >= N_SHARDS) return;
+    collect_counts(counts, totals, n_lights);
+}
 
 // (the accumulation frame is left at zero: the next frame of the context starts from it)
-__global__ __launch_bounds__(256) void k_finalize(double *accum, long long n_values, int spp, double *out_f64, uint8_t *out_u8)
+// The frame's last kernel also hands the totals to the host: its first wave rolls up the counters of a frame that was one
+// launch (`counts`, else null: the batches' own roll-ups have run) and copies the totals to `host_totals` (pinned memory).
+__global__ __launch_bounds__(256) void k_finalize(double *accum, long long n_values, int spp, double *out_f64, uint8_t *out_u8,
+                                                  const uint32_t *counts, unsigned long long *totals, unsigned long long *host_totals,
+                                                  int n_lights)
 {
+    if (blockIdx.x == 0 && threadIdx.x < N_SHARDS) {
+        if (counts) collect_counts(counts, totals, n_lights);
+        if (threadIdx.x == 0)
+            for (int k = 0; k < 16; ++k) host_totals[k] = totals[k];
+    }
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride) {
         double c = accum[i] / (double)spp;

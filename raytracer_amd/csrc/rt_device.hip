@@ -1126,6 +1126,21 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     int block = want_local ? ctx->dbg.local_threads : (noalloc || use_fused || batch_chunks * 64 <= (1ll << 22)) ? 256 : RT_BLOCK;
     if (!use_fused && (ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024)) block = ctx->dbg.block_threads;
     const int blocks_per_cu = 1024 / block, waves_per_block = block / 64;
+    // k_local: primary chunks per block (one run per resident wave slot) and the records a block's ray list can hold
+    // (with two rays per hit, `growth` times the first generation, as in plan_queues); beside its counters the block keeps
+    // a word per 64 records of the ray lists of generations 1..5 in LDS
+    long long local_cpb = 0, local_cap = 0, local_grid = 0;
+    size_t local_lds = 0;
+    bool local_fits = want_local;
+    if (want_local) {
+        const long long slots = (long long)waves_per_block * ctx->cu_count * blocks_per_cu;
+        const long long k = (n_chunks + slots - 1) / slots;
+        local_cpb = waves_per_block * k;
+        local_grid = (n_chunks + local_cpb - 1) / local_cpb;
+        local_cap = local_cpb * 64 * (ctx->any_transparent ? (long long)ctx->growth : 1ll);
+        local_lds = (size_t)(CNT_WORDS + 32 + 5 * (local_cap / 64)) * sizeof(uint32_t);
+        if (local_lds > 24 * 1024) local_fits = false;       // (deep queues after overflows: the launch-per-pass path takes over)
+    }
     P.S.stack_shift = block == 256 ? 8 : (block == 512 ? 9 : 10);
     // LDS per block: the stacks, the material and light tables, then as many top-of-tree nodes as fit
     // beside them when the compute unit holds 1024 threads (the register budget allows four waves per SIMD).
@@ -1147,7 +1162,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const size_t lds_tables = (size_t)(P.S.mat_cached + P.S.light_cached) * 64;
     {
         const size_t per_block = lds_block;
-        const size_t fixed = lds_stack + lds_tables + 128 + 512 + (want_local ? (CNT_WORDS + 32) * sizeof(uint32_t) : 0);
+        const size_t fixed = lds_stack + lds_tables + 128 + 512 + (local_fits ? local_lds : 0);
         long long room = per_block > fixed ? (long long)((per_block - fixed) / (NODE_LDS_WORDS * 4)) : 0;
         if (ctx->dbg.node_cache >= 0 && ctx->dbg.node_cache < room) room = ctx->dbg.node_cache;
         // the triangle hierarchy first, the sphere hierarchy takes what is left; split evenly when both are large
@@ -1176,9 +1191,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     // every traversal kernel gets the same layout (the octree-walk variants use the tables only)
     const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int) +
                            (size_t)P.S.btri_cached * 80 + lds_tables + 128 + 32;
-    bool use_local = want_local && bvh_closest_ok && bvh_shadow_ok;      // (and its queues within the memory budget, below)
+    bool use_local = local_fits && bvh_closest_ok && bvh_shadow_ok;      // (and its queues within the memory budget, below)
     const int lds_counts_word = P.S.lds_ticket_word + 8;                 // k_local: the block's own queue counters
-    const size_t lds_local = lds_bvh + (CNT_WORDS + 32) * sizeof(uint32_t);
+    const size_t lds_local = lds_bvh + local_lds;
     const size_t lds_closest = lds_bvh;
     const size_t lds_shadow = lds_bvh;
     const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
@@ -1203,17 +1218,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     };
     long long fused_defer_cap = 0;
     LocalPlan LP{};
-    long long local_grid = 0, local_cap = 0;
     if (use_local) {
-        // one block per compute unit when the frame has that many runs of sixteen chunks; a block's queues hold what its
-        // own samples can spawn (with two rays per hit, `growth` times the first generation, as in plan_queues)
-        const long long slots = (long long)waves_per_block * ctx->cu_count * blocks_per_cu;     // resident waves
-        const long long k = (n_chunks + slots - 1) / slots;
-        const long long cpb = waves_per_block * k;
-        LP.chunks_per_block = (uint32_t)cpb;
-        local_grid = (n_chunks + cpb - 1) / cpb;
-        local_cap = cpb * 64 * (fan_out > 1 ? (long long)ctx->growth : 1ll);
-        const size_t bytes = (size_t)(local_grid * local_cap) * (2 * sizeof(RayRec) + 6 * (all_flat ? 64 : sizeof(HitRec)));
+        LP.chunks_per_block = (uint32_t)local_cpb;
+        const size_t bytes = (size_t)(local_grid * local_cap) * (7 * sizeof(RayRec) + 6 * (all_flat ? 64 : sizeof(HitRec)));
         if (bytes > ctx->queue_budget) use_local = false;        // the launch-per-pass path cuts the frame into batches
     }
     if (use_fused) {
@@ -1239,10 +1246,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         const size_t hit_stride = all_flat ? 64 : sizeof(HitRec);
         int rc;
         if ((rc = ensure(&ctx->accum, &ctx->accum_values, n_pixels * 3)) != RT_OK) return rc;
-        for (int kk = 0; kk < 2; ++kk) {
-            if ((rc = ensure(&ctx->rays[kk], &ctx->ray_capacity[kk], (size_t)(local_grid * cap))) != RT_OK) return rc;
-            LP.rays[kk] = ctx->rays[kk];
-        }
+        if ((rc = ensure(&ctx->rays[0], &ctx->ray_capacity[0], (size_t)(7 * local_grid * cap))) != RT_OK) return rc;
+        LP.rays = ctx->rays[0];
         // a hit slice per generation: shadow chunks are taken whenever a wave has nothing to trace, so a generation's hits
         // may still be waiting when the generation after the next is being traced
         if ((rc = ensure(&ctx->hits[0], &ctx->hit_capacity[0], ((size_t)(6 * local_grid * cap) * hit_stride + sizeof(HitRec) - 1) / sizeof(HitRec))) != RT_OK) return rc;
@@ -1449,8 +1454,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             if (ev) HIP_TRY(hipEventRecord(ev->first, st));
             hipLaunchKernelGGL((k_local<SHADOW_BVH>), dim3((unsigned)local_grid), dim3(block), lds_local, st, P, Q, LP);
             if (ev) HIP_TRY(hipEventRecord(ev->second, st));
-            hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, counts, B.totals, P.S.n_lights);
-            ctx->pending_batches++;
+            ctx->pending_batches++;      // (k_finalize rolls the counters up)
             batch_no = 1;
             HIP_TRY(hipEventRecord(ctx->ev_batch[0], st));
         } else
@@ -1614,7 +1618,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             long long blocks = (n_values + 255) / 256;
             if (blocks > max_blocks_256) blocks = max_blocks_256;
             hipLaunchKernelGGL(k_finalize, dim3((unsigned)blocks), dim3(256), 0, st, B.accum, n_values, N * N,
-                               static_cast<double *>(dev[0]), static_cast<uint8_t *>(dev[1]));
+                               static_cast<double *>(dev[0]), static_cast<uint8_t *>(dev[1]),
+                               use_local ? (const uint32_t *)B.counts : (const uint32_t *)nullptr, B.totals, ctx->h_totals, (int)P.S.n_lights);
             HIP_TRY(hipGetLastError());
             if (B.accum == ctx->accum) { ctx->accum_clean = (size_t)n_values; ctx->accum_clean_ptr = ctx->accum; }
         }
@@ -1622,7 +1627,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             for (int k = 0; k < 4; ++k)
                 if (dst[k]) HIP_TRY(hipMemcpyAsync(dst[k], dev[k], bytes[k], hipMemcpyDeviceToHost, st));
     }
-    HIP_TRY(hipMemcpyAsync(ctx->h_totals, B.totals, RT_TOTALS_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (local_rows <= 0)     // (else k_finalize has handed them over)
+        HIP_TRY(hipMemcpyAsync(ctx->h_totals, B.totals, RT_TOTALS_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(ctx->ev_end, st));
     ctx->pending = true;
     return RT_OK;

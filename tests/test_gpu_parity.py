@@ -304,6 +304,32 @@ def test_self_contained_blocks_agree_with_the_passes(gpu, oracle_frame, scene, r
     assert frames[0]["stats"]["hits_per_generation"] == frames[1]["stats"]["hits_per_generation"]
 
 
+@pytest.mark.parametrize("scene,res,n", [("gears", (192, 160), 2), ("refract", (256, 256), 1), ("balls", (200, 200), 1)])
+def test_self_contained_blocks_are_repeatable(gpu, scene, res, n):
+    """The waves of a self-contained block hand work to each other through counters in LDS, with no barrier; a chunk taken
+    before what it reads is written, or a list overwritten while it is still read, would show as a run whose ray counts
+    or pixels differ.  Every block size, many runs, against the launch-per-pass frame."""
+    s = load_scene(gpu, scene)
+    cam = s.camera(*res)
+    gpu.set_option("fused", 0)
+    try:
+        gpu.set_option("local", 0)
+        ref = gpu.render(cam, num_samples=n, flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+        gpu.set_option("local", 1)
+        for threads in (1024, 512, 256):
+            gpu.set_option("local_threads", threads)
+            for _ in range(12):
+                f = gpu.render(cam, num_samples=n, flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+                assert f["stats"]["rays_per_generation"] == ref["stats"]["rays_per_generation"], threads
+                assert f["stats"]["shadow_rays"] == ref["stats"]["shadow_rays"], threads
+                assert np.array_equal(f["rgb_u8"], ref["rgb_u8"]), threads
+                assert np.abs(f["rgb_f64"] - ref["rgb_f64"]).max() <= 1e-9, threads
+    finally:
+        gpu.set_option("local", -1)
+        gpu.set_option("local_threads", 1024)
+        gpu.set_option("fused", -1)
+
+
 def test_primary_pass_in_units_drawn_while_it_runs(gpu, oracle_frame):
     """A primary pass with many chunks per wave hands its chunks out in units while it runs (a counter in memory, a
     permuted order, records sharded by unit) instead of giving every block a fixed share: the same frame and ray counts
