@@ -222,22 +222,28 @@ __global__ __launch_bounds__(256) void k_next_owner(const unsigned long long *ke
     owner[j] = next;
 }
 
-// After the last level: every node's weight sum (one wave per node) and its children's leaf flags.
-__global__ __launch_bounds__(256) void k_finish_nodes(lightcam::Node *nodes, int n_nodes, const lightcam::Point *pts)
+// After the last level, level by level from the deepest up: a node's weight sum is the sum of its children's (already
+// formed) plus that of the points it keeps itself, and its children's leaf flags.  One wave per node; nodes [first, first +
+// count) are one level.  (Summing every node's whole range instead made the few nodes at the top, which span all points,
+// a serial tail of 4 ms per set-up.)
+__global__ __launch_bounds__(256) void k_finish_level(lightcam::Node *nodes, int first, int count, const lightcam::Point *pts)
 {
     const int lane = (int)(threadIdx.x & 63);
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
-    for (long long k = wave; k < n_nodes; k += n_waves) {
-        const int b = nodes[k].begin, e = nodes[k].end;
+    for (long long k = first + wave; k < (long long)first + count; k += n_waves) {
+        const int b = nodes[k].rest_begin, e = nodes[k].end;
         double s = 0;
         for (int i = b + lane; i < e; i += 64) s += pts[i].w;
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
         int bits = 0;
         if (lane < 8) {
             const int ch = nodes[k].child[lane];
-            if (ch >= 0 && nodes[ch].leaf) bits = 1 << lane;
+            if (ch >= 0) {
+                s += nodes[ch].wsum;
+                if (nodes[ch].leaf) bits = 1 << lane;
+            }
         }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
         for (int off = 4; off > 0; off >>= 1) bits |= __shfl_xor(bits, off);
         if (lane == 0) { nodes[k].wsum = s; nodes[k].child_leaf = bits; }
     }

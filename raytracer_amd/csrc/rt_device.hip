@@ -635,6 +635,8 @@ static int build_trees_on_device(rt_ctx *ctx, hipStream_t st, lightcam::Point *d
     HIP_TRY(hipMemcpyAsync(&h, ctr, sizeof h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     int cur = 0, levels = 0;        // pts[cur], owner[cur], active[cur] are the current level's
+    int32_t level_end = n_trees;             // nodes created so far, as of the last level read back
+    std::vector<int32_t> level_first{0};     // nodes are numbered level by level: level l is [level_first[l], level_first[l + 1])
     while (h.n_next > 0) {
         const int n_active = h.n_next;
         if ((size_t)h.n_nodes + 8 * (size_t)n_active > cap) return fail(RT_ERR_CAPACITY, "light-camera trees: node workspace too small");
@@ -653,11 +655,18 @@ static int build_trees_on_device(rt_ctx *ctx, hipStream_t st, lightcam::Point *d
         HIP_TRY(hipMemcpyAsync(&h, ctr, sizeof h, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (h.overflow) return fail(RT_ERR_CAPACITY, "light-camera trees: node workspace too small");
+        level_first.push_back(level_end);
+        level_end = h.n_nodes;
         cur ^= 1;
         if (++levels > 80) return fail(RT_ERR_DEVICE, "light-camera trees: the build does not terminate");
     }
-    hipLaunchKernelGGL(lcdev::k_finish_nodes, dim3((unsigned)(h.n_nodes < 4096 ? (h.n_nodes + 3) / 4 : 1024)), dim3(256), 0, st, nodes, h.n_nodes,
-                       pts[cur]);
+    level_first.push_back(level_end);
+    for (int l = (int)level_first.size() - 2; l >= 0; --l) {
+        const int first = level_first[l], count = level_first[l + 1] - first;
+        if (count <= 0) continue;
+        hipLaunchKernelGGL(lcdev::k_finish_level, dim3((unsigned)(count < 4096 ? (count + 3) / 4 : 1024)), dim3(256), 0, st, nodes, first, count,
+                           pts[cur]);
+    }
     HIP_TRY(hipGetLastError());
     void *dn = nullptr, *dp = nullptr;
     HIP_TRY(hipMalloc(&dn, sizeof(lightcam::Node) * (size_t)h.n_nodes));
