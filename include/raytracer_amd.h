@@ -210,7 +210,10 @@ int rt_noalloc_scratch_bytes(size_t *bytes);
 
 /* Diagnostic: experiment switches of one context, none of which changes a result.  Names: "block_threads" (256 or
  * 1024, 0 = per-frame choice), "node_cache", "tri_cache" (caps on what is copied into LDS, -1 = none), "rounds",
- * "verbose", "queue_growth" (1..32), and for the next rt_upload_scene "leaf_max" (1..4), "split_budget" (percent). */
+ * "verbose", "queue_growth" (1..32); "pair", "overlap", "fused", "local" (1 forces, 0 forbids, -1 leaves to the frame's
+ * size: paired passes, passes on two streams, the lane-per-sample kernel, the self-contained blocks), "local_threads"
+ * (256, 512, 1024), "units" (0: the primary pass keeps fixed shares per block), "lightcam_host" (1: light-camera trees
+ * built on the host); and for the next rt_upload_scene "leaf_max" (1..4), "split_budget" (percent). */
 int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value);
 
 /* ---- several GPUs of one node ----

@@ -72,7 +72,7 @@ void *g_scratch_ptr[RT_MAX_DEVICES] = {};       // per device: address of that d
 #define RT_DEFAULT_QUEUE_BUDGET ((size_t)32 << 30)
 // Frames of at most this many samples run as one launch per batch (k_fused) instead of the wavefront pipeline.
 #define RT_FUSED_MAX_SAMPLES (1ll << 20)
-#define RT_LOCAL_MAX_SAMPLES (1ll << 19)     // frames up to this many samples run as one launch of self-contained blocks (k_local)
+#define RT_LOCAL_MAX_SAMPLES (1ll << 21)     // frames up to this many samples run as one launch of self-contained blocks (k_local)
 
 // Experiment switches (rt_debug_set_option); the defaults are what the product runs.
 struct DebugOptions {
