@@ -147,7 +147,7 @@ DEV TriOps load_leaf_tri(const DevScene &S, int k)
     v2d a, b, c, e, f;
     if (k < S.btri_cached) {
         const __attribute__((address_space(3))) v2d *p =
-            (const __attribute__((address_space(3))) v2d *)((__attribute__((address_space(3))) const int *)s_lds + (S.lds_tri_word + k * 20));
+            (const __attribute__((address_space(3))) v2d *)((__attribute__((address_space(3))) const int *)s_lds + (S.lds_tri_word + (int)__umul24((unsigned)k, 20u)));
         a = p[0]; b = p[1]; c = p[2]; e = p[3]; f = p[4];
     } else {
         const __attribute__((address_space(1))) v2d *p = (const __attribute__((address_space(1))) v2d *)&S.btri[k];
@@ -238,7 +238,8 @@ DEV void box4_test(const accel::Bvh4Node *nodes, int cached, int lds_word, int c
     v4f nx, fx, ny, fy, nz, fz;
     v4i code;
     if (cur < cached) {
-        __attribute__((address_space(3))) const int *lw = (__attribute__((address_space(3))) const int *)s_lds + (lds_word + cur * NODE_LDS_WORDS);
+        // (a 24-bit multiply issues at full rate, the 32-bit one at a quarter)
+        __attribute__((address_space(3))) const int *lw = (__attribute__((address_space(3))) const int *)s_lds + (lds_word + (int)__umul24((unsigned)cur, NODE_LDS_WORDS));
         nx = *(lds_v4f *)(lw + (r.sx >> 2));
         fx = *(lds_v4f *)(lw + ((r.sx ^ 16u) >> 2));
         ny = *(lds_v4f *)(lw + (r.sy >> 2));

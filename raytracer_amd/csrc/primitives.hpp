@@ -82,6 +82,8 @@ struct TriGate {
     bool inside;     // alpha and beta pass the reference's tests, for sure (t still to be judged)
     bool early;      // the first barycentric coordinate ruled the triangle out for every lane testing one
 };
+// v * sign(detA), by the sign bit (sgn = the sign bit of detA's high word): -0 and NaN pass through as they should
+DEV double tri_flip(double v, uint32_t sgn) { return __hiloint2double((int)((uint32_t)__double2hiint(v) ^ sgn), __double2loint(v)); }
 DEV TriGate tri_gate(const TriOps &tr, d3 o, d3 d, double *Xo, double *Yo)
 {
     TriGate g;
@@ -94,25 +96,30 @@ DEV TriGate tri_gate(const TriOps &tr, d3 o, d3 d, double *Xo, double *Yo)
     const double m4 = d.y * ae.z - ae.y * d.z;
     const double m5 = ae.y * ac.z - ac.y * ae.z;
     const double X = ae.x * m1 + ac.x * m4 + d.x * m5;          // det3(ae, ac, d)
+    const uint32_t sgn = (uint32_t)__double2hiint(detA) & 0x80000000u;
     const double ad = fabs(detA);
+    // |detA| in a range where a quotient by it neither overflows to a wrong side of a threshold nor underflows to zero: a
+    // numerator below -1e-150 then gives a quotient below zero, an infinite one compares like the infinite quotient would,
+    // and a NaN fails every comparison below, which sends the lane to the exact sequence
     const bool ranged = ad > 1e-150 && ad < 1e150;
-    const double sX = detA < 0 ? -X : X;
+    const double sX = tri_flip(X, sgn);
+    const double up = ad * (1.0 + 0x1p-40);
     g.detA = detA; g.ad = ad; g.Z = 0; g.sZ = 0; g.inside = false;
     *Xo = X; *Yo = 0;
     // When the first barycentric coordinate alone rules the triangle out for every lane of the wave that is
     // testing one, the other two determinants are not formed (neighbouring rays mostly agree on that).
-    g.miss = ranged && fabs(X) < 1e150 && (sX < -1e-150 || sX > ad * (1.0 + 0x1p-40));
-    g.early = __ballot(!g.miss) == 0;
+    const bool miss_x = ranged && (sX < -1e-150 || sX > up);
+    g.miss = miss_x;
+    g.early = __ballot(!miss_x) == 0;
     if (g.early) return g;
     const double m6 = ab.y * ae.z - ae.y * ab.z;
     const double Y = ab.x * (-m4) + ae.x * m2 + d.x * m6;       // det3(ab, ae, d)
     const double Z = ab.x * (-m5) + ac.x * (-m6) + ae.x * m3;   // det3(ab, ac, ae)
-    const double sY = detA < 0 ? -Y : Y;
-    const bool fin = ranged && fabs(X) < 1e150 && fabs(Y) < 1e150 && fabs(Z) < 1e150;
+    const double sY = tri_flip(Y, sgn);
     const double sum = sX + sY;
-    g.miss = fin && (sX < -1e-150 || sX > ad * (1.0 + 0x1p-40) || sY < -1e-150 || sum > ad * (1.0 + 0x1p-30));
-    g.inside = fin && sX >= 0 && sX <= ad && sY >= 0 && sum <= ad * (1.0 - 0x1p-30);
-    g.Z = Z; g.sZ = detA < 0 ? -Z : Z;
+    g.miss = miss_x || (ranged && (sY < -1e-150 || sum > ad * (1.0 + 0x1p-30)));
+    g.inside = ranged && sX >= 0 && sX <= ad && sY >= 0 && sum <= ad * (1.0 - 0x1p-30);
+    g.Z = Z; g.sZ = tri_flip(Z, sgn);
     *Yo = Y;
     return g;
 }
@@ -134,7 +141,7 @@ DEV double tri_test_fast(const TriOps &tr, d3 o, d3 d, double minT, double maxT,
     const TriGate g = tri_gate(tr, o, d, &X, &Y);
     if (g.early) return maxT;
     // a hit for sure farther than tcut, or nearer than minT, needs no quotient either
-    const bool wanted = g.inside && !(g.sZ < (minT * g.ad) * (1.0 - 0x1p-40) || g.sZ > (tcut * g.ad) * (1.0 + 0x1p-40));
+    const bool wanted = g.inside && !(g.sZ < g.ad * (minT * (1.0 - 0x1p-40)) || g.sZ > (tcut * g.ad) * (1.0 + 0x1p-40));
     double t = maxT;
     const bool exact = !(g.miss || g.inside);
     if (__ballot(wanted)) {
@@ -155,9 +162,10 @@ DEV bool tri_any_fast(const TriOps &tr, d3 o, d3 d, double minT, double maxT)
     double X, Y;
     const TriGate g = tri_gate(tr, o, d, &X, &Y);
     if (g.early) return false;
-    const double lo = minT * g.ad, hi = maxT * g.ad;
-    const bool t_out = g.sZ < lo * (1.0 - 0x1p-40) || g.sZ > hi * (1.0 + 0x1p-40);
-    const bool t_in = g.sZ >= lo * (1.0 + 0x1p-40) && g.sZ <= hi * (1.0 - 0x1p-40);
+    // (the margins of 2^-40 dwarf the roundings of these products, whichever way they are associated)
+    const double hi = maxT * g.ad;
+    const bool t_out = g.sZ < g.ad * (minT * (1.0 - 0x1p-40)) || g.sZ > hi * (1.0 + 0x1p-40);
+    const bool t_in = g.sZ >= g.ad * (minT * (1.0 + 0x1p-40)) && g.sZ <= hi * (1.0 - 0x1p-40);
     bool hit = g.inside && t_in;
     const bool exact = !(g.miss || (g.inside && (t_in || t_out)));
     if (__ballot(exact)) {
