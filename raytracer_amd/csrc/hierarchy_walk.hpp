@@ -49,7 +49,8 @@ DEV void stamp_at(int k, int sel)
 #define STAMP(k) ((void)0)
 #endif
 
-// Stack of pending nodes in LDS: entry k of a lane lives at stack[k * block size + thread-in-block], so a
+// Stack of pending nodes in LDS: entry k of a lane lives at stack[k * block size + thread-in-block] (the walks keep the
+// offset k * block size itself and add a block size per push), so a
 // wave's push or pop touches 64 consecutive banks.
 #define BVH_STACK 64
 #define BVH_NONE (-1)
@@ -224,8 +225,10 @@ DEV float limit_f32(double limit)
 
 // Conservative entry distances of the four children of node `cur` (+inf: missed within
 // [0, limit] or no child), and their codes.  The first `cached` nodes of this hierarchy start at LDS word `lds_word`.
+// HITS_ONLY: h[i] says whether child i is hit and k is left alone (a query that visits in any order needs no distances).
+template <bool HITS_ONLY>
 DEV void box4_test(const accel::Bvh4Node *nodes, int cached, int lds_word, int cur, const RayBox4 &r, float limitf,
-                   float k[4], int c[4])
+                   float k[4], int c[4], bool h[4])
 {
     // The two sources are read through pointers of explicit address spaces: with generic pointers the
     // compiler merges the branches into flat loads, which take the slow path for LDS addresses.
@@ -266,7 +269,8 @@ DEV void box4_test(const accel::Bvh4Node *nodes, int cached, int lds_word, int c
         const float tf = fminf(fminf(fminf(__builtin_fmaf(fx.m, r.ix, -r.cfx), __builtin_fmaf(fy.m, r.iy, -r.cfy)), \
                                      __builtin_fmaf(fz.m, r.iz, -r.cfz)), limitf);                                 \
         c[i] = code.m;                                                                                            \
-        k[i] = (code.m != BVH_NONE && tn <= tf * (1.0f + 0x1p-17f)) ? tn : inf;                                    \
+        if (HITS_ONLY) h[i] = code.m != BVH_NONE && tn <= tf * (1.0f + 0x1p-17f);                                  \
+        else k[i] = (code.m != BVH_NONE && tn <= tf * (1.0f + 0x1p-17f)) ? tn : inf;                               \
     } while (0)
     BOX4_CHILD(0, x);
     BOX4_CHILD(1, y);
@@ -286,45 +290,47 @@ DEV void box4_test(const accel::Bvh4Node *nodes, int cached, int lds_word, int c
 
 // One step down from inner node `cur`: tests its (up to) four child boxes, continues with the
 // nearest hit child and stacks the others, farthest first (or pops when nothing is hit).
+template <bool ORDERED>
 DEV int bvh4_step(const accel::Bvh4Node *nodes, int cached, int lds_word, int cur, const RayBox4 &rb, float limitf,
-                  bool ordered, int *stack, int &sp, int ss)
+                  int *stack, int &sp, int step)
 {
-    float kk[4];
+    float kk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     int cc[4];
-    box4_test(nodes, cached, lds_word, cur, rb, limitf, kk, cc);
+    bool hh[4] = {false, false, false, false};
+    box4_test<!ORDERED>(nodes, cached, lds_word, cur, rb, limitf, kk, cc, hh);
     float k0 = kk[0], k1 = kk[1], k2 = kk[2], k3 = kk[3];
     int c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3];
     const float inf = __builtin_inff();
-    if (ordered) {
+    if (ORDERED) {
         // no lane of the wave has two hit children: nothing to order, nothing to stack
         const int nh = (k0 < inf) + (k1 < inf) + (k2 < inf) + (k3 < inf);
         if (__ballot(nh >= 2) == 0) {
             if (nh) return k0 < inf ? c0 : (k1 < inf ? c1 : (k2 < inf ? c2 : c3));
             if (sp == 0) return BVH_NONE;
-            --sp;
-            return stack[sp << ss];
+            sp -= step;
+            return stack[sp];
         }
         BVH_SORT2(k0, c0, k1, c1);
         BVH_SORT2(k2, c2, k3, c3);
         BVH_SORT2(k0, c0, k2, c2);
         BVH_SORT2(k1, c1, k3, c3);
         BVH_SORT2(k1, c1, k2, c2);
-        if (k3 < inf) { stack[sp << ss] = c3; ++sp; }
-        if (k2 < inf) { stack[sp << ss] = c2; ++sp; }
-        if (k1 < inf) { stack[sp << ss] = c1; ++sp; }
+        if (k3 < inf) { stack[sp] = c3; sp += step; }
+        if (k2 < inf) { stack[sp] = c2; sp += step; }
+        if (k1 < inf) { stack[sp] = c1; sp += step; }
         if (k0 < inf) return c0;
     } else {
         // any order: the last hit child is kept in hand, the others go to the stack
         int next = BVH_NONE;
-        if (k0 < inf) next = c0;
-        if (k1 < inf) { if (next != BVH_NONE) { stack[sp << ss] = next; ++sp; } next = c1; }
-        if (k2 < inf) { if (next != BVH_NONE) { stack[sp << ss] = next; ++sp; } next = c2; }
-        if (k3 < inf) { if (next != BVH_NONE) { stack[sp << ss] = next; ++sp; } next = c3; }
+        if (hh[0]) next = c0;
+        if (hh[1]) { if (next != BVH_NONE) { stack[sp] = next; sp += step; } next = c1; }
+        if (hh[2]) { if (next != BVH_NONE) { stack[sp] = next; sp += step; } next = c2; }
+        if (hh[3]) { if (next != BVH_NONE) { stack[sp] = next; sp += step; } next = c3; }
         if (next != BVH_NONE) return next;
     }
     if (sp == 0) return BVH_NONE;
-    --sp;
-    return stack[sp << ss];
+    sp -= step;
+    return stack[sp];
 }
 
 struct Best {
@@ -344,7 +350,7 @@ DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb
     if ((TRI ? S.n_tri_nodes : S.n_sph_nodes) == 0) return;
     const int cached = TRI ? S.tri_cached : S.sph_cached;
     const int lds_word = S.lds_cache_word + (TRI ? 0 : S.tri_cached * NODE_LDS_WORDS);
-    const int ss = S.stack_shift;
+    const int step = 1 << S.stack_shift;      // entries of one lane lie a block apart; sp counts in ints
     int cur = 0, sp = 0;
     while (true) {
         const float limitf = limit_f32(best.t * (1.0 + 1e-12) + 1e-12);
@@ -352,7 +358,7 @@ DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb
         while (cur >= 0) {
             WC_ADD(wc, lane_nodes);
             WC_WAVE(wc, wave_nodes);
-            cur = bvh4_step(nodes, cached, lds_word, cur, rb, limitf, true, stack, sp, ss);
+            cur = bvh4_step<true>(nodes, cached, lds_word, cur, rb, limitf, stack, sp, step);
         }
         if (cur == BVH_NONE) break;
         WC_ADD(wc, lane_leaves);
@@ -370,8 +376,8 @@ DEV void bvh_closest(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb
             }
         }
         if (sp == 0) break;
-        --sp;
-        cur = stack[sp << ss];
+        sp -= step;
+        cur = stack[sp];
     }
 }
 
@@ -385,7 +391,7 @@ DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, in
     if ((TRI ? S.n_tri_nodes : S.n_sph_nodes) == 0) return false;
     const int cached = TRI ? S.tri_cached : S.sph_cached;
     const int lds_word = S.lds_cache_word + (TRI ? 0 : S.tri_cached * NODE_LDS_WORDS);
-    const int ss = S.stack_shift;
+    const int step = 1 << S.stack_shift;      // entries of one lane lie a block apart; sp counts in ints
     const float limitf = limit_f32(maxT * (1.0 + 1e-12) + 1e-12);
     int cur = 0, sp = 0;
     while (true) {
@@ -393,7 +399,7 @@ DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, in
         while (cur >= 0) {
             WC_ADD(wc, lane_nodes);
             WC_WAVE(wc, wave_nodes);
-            cur = bvh4_step(nodes, cached, lds_word, cur, rb, limitf, false, stack, sp, ss);
+            cur = bvh4_step<false>(nodes, cached, lds_word, cur, rb, limitf, stack, sp, step);
         }
         if (cur == BVH_NONE) break;
         WC_ADD(wc, lane_leaves);
@@ -411,8 +417,8 @@ DEV bool bvh_any(const DevScene &S, d3 o, d3 d, double d2, const RayBox4 &rb, in
             }
         }
         if (sp == 0) break;
-        --sp;
-        cur = stack[sp << ss];
+        sp -= step;
+        cur = stack[sp];
     }
     return false;
 }
