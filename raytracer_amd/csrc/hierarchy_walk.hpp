@@ -225,7 +225,7 @@ DEV float limit_f32(double limit)
 
 // Conservative entry distances of the four children of node `cur` (+inf: missed within
 // [0, limit] or no child), and their codes.  The first `cached` nodes of this hierarchy start at LDS word `lds_word`.
-// HITS_ONLY: h[i] says whether child i is hit and k is left alone (a query that visits in any order needs no distances).
+// h[i] says whether child i is hit; with HITS_ONLY k is left alone (a query that visits in any order needs no distances).
 template <bool HITS_ONLY>
 DEV void box4_test(const accel::Bvh4Node *nodes, int cached, int lds_word, int cur, const RayBox4 &r, float limitf,
                    float k[4], int c[4], bool h[4])
@@ -269,8 +269,8 @@ DEV void box4_test(const accel::Bvh4Node *nodes, int cached, int lds_word, int c
         const float tf = fminf(fminf(fminf(__builtin_fmaf(fx.m, r.ix, -r.cfx), __builtin_fmaf(fy.m, r.iy, -r.cfy)), \
                                      __builtin_fmaf(fz.m, r.iz, -r.cfz)), limitf);                                 \
         c[i] = code.m;                                                                                            \
-        if (HITS_ONLY) h[i] = code.m != BVH_NONE && tn <= tf * (1.0f + 0x1p-17f);                                  \
-        else k[i] = (code.m != BVH_NONE && tn <= tf * (1.0f + 0x1p-17f)) ? tn : inf;                               \
+        h[i] = code.m != BVH_NONE && tn <= tf * (1.0f + 0x1p-17f);                                                 \
+        if (!HITS_ONLY) k[i] = h[i] ? tn : inf;                                                                   \
     } while (0)
     BOX4_CHILD(0, x);
     BOX4_CHILD(1, y);
@@ -303,9 +303,9 @@ DEV int bvh4_step(const accel::Bvh4Node *nodes, int cached, int lds_word, int cu
     const float inf = __builtin_inff();
     if (ORDERED) {
         // no lane of the wave has two hit children: nothing to order, nothing to stack
-        const int nh = (k0 < inf) + (k1 < inf) + (k2 < inf) + (k3 < inf);
+        const int nh = (int)hh[0] + (int)hh[1] + (int)hh[2] + (int)hh[3];
         if (__ballot(nh >= 2) == 0) {
-            if (nh) return k0 < inf ? c0 : (k1 < inf ? c1 : (k2 < inf ? c2 : c3));
+            if (nh) return hh[0] ? c0 : (hh[1] ? c1 : (hh[2] ? c2 : c3));
             if (sp == 0) return BVH_NONE;
             sp -= step;
             return stack[sp];
