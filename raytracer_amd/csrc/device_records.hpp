@@ -135,6 +135,7 @@ struct FrameParams {
 #define CNT_DEFER(g) ((13 + (g)) * N_SHARDS)     // g = 0..5: deferred light-camera evaluations
 #define CNT_OVERFLOW (19 * N_SHARDS)
 #define CNT_UNITS (19 * N_SHARDS + 4)            // units of work handed out by a primary pass that shares its chunks out on the device
+#define CNT_LCWORK (19 * N_SHARDS + 5)           // 64-query chunks handed out by the light-camera density pass
 #define CNT_WORDS (19 * N_SHARDS + 16)
 
 struct QueueSet {

@@ -953,11 +953,13 @@ struct LightcamQueues {
     uint32_t shard_cap[6];
     const uint32_t *counts;
     uint32_t *overflow;          // the frame's "incomplete" word
+    uint32_t *next_chunk;        // chunks handed out so far (zero at launch)
 };
-__global__ __launch_bounds__(256) void k_lightcam(FrameParams P, LightcamQueues L)
+#ifndef LC_MIN_WAVES
+#define LC_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(LC_BLOCK, LC_MIN_WAVES) void k_lightcam(FrameParams P, LightcamQueues L)
 {
-    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
     ShardMap smap[6];
     long long first[7];
     first[0] = 0;
@@ -966,7 +968,12 @@ __global__ __launch_bounds__(256) void k_lightcam(FrameParams P, LightcamQueues 
         smap[g] = shard_map(&L.counts[CNT_DEFER(g)], L.shard_cap[g], 1u);
         first[g + 1] = first[g] + (long long)smap[g].total;
     }
-    for (long long work = wave; work < first[6]; work += n_waves) {
+    // chunks differ in length by a factor of five: waves draw them from a counter, in order, instead of keeping to a fixed share
+    for (;;) {
+        uint32_t drawn = 0;
+        if ((threadIdx.x & 63) == 0) drawn = atomicAdd(L.next_chunk, 1u);
+        const long long work = (long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
+        if (work >= first[6]) break;
         int g = 0;
 #pragma unroll
         for (int k = 1; k < 6; ++k) if (work >= first[k]) g = k;

@@ -1211,6 +1211,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const int rounds = ctx->dbg.rounds > 0 ? ctx->dbg.rounds : 2;        // rounds of resident blocks a queued pass is cut into
     int max_blocks = ctx->cu_count * rounds * blocks_per_cu;
     const int max_blocks_256 = ctx->cu_count * 8;                        // the same for kernels with 256-thread blocks
+    const int lightcam_blocks = ctx->cu_count * 16 * 64 / LC_BLOCK;      // sixteen waves of density queries per compute unit
     const long long fan_out = ctx->any_transparent ? 2 : 1;
     QueuePlan QP;
     FrameBuffers B;
@@ -1442,7 +1443,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     L.shard_cap[0] = (uint32_t)fused_defer_cap;
                     L.counts = counts;
                     L.overflow = &counts[CNT_OVERFLOW];
-                    hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks_256), dim3(256), 0, st, P, L);
+                    L.next_chunk = &counts[CNT_LCWORK];
+                    hipLaunchKernelGGL(k_lightcam, dim3((unsigned)lightcam_blocks), dim3(LC_BLOCK), 0, st, P, L);
                 }
                 hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, counts, B.totals, P.S.n_lights);
                 ctx->pending_batches++;
@@ -1612,7 +1614,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 for (int g = 0; g < 6; ++g) { L.deferred[g] = B.deferred[g]; L.shard_cap[g] = (uint32_t)(hit_cap[g] * QP.defer_mult); }
                 L.counts = counts;
                 L.overflow = &counts[CNT_OVERFLOW];
-                hipLaunchKernelGGL(k_lightcam, dim3((unsigned)max_blocks_256), dim3(256), 0, sb, P, L);
+                L.next_chunk = &counts[CNT_LCWORK];
+                hipLaunchKernelGGL(k_lightcam, dim3((unsigned)lightcam_blocks), dim3(LC_BLOCK), 0, sb, P, L);
             }
             hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, sb, counts, B.totals, P.S.n_lights);
             HIP_TRY(hipEventRecord(ctx->ev_batch[par], sb));

@@ -34,13 +34,13 @@ for gi, gname in enumerate(("primary", "queued", "shadow")):
 q = list(buf[24:32])
 if q[0]:
     n = q[0]
-    print("lightcam queries %d | per query: descent nodes %.1f, cells inside reached nodes %.1f (most for one query %d), whole-cell sums %.1f, "
-          "points tested %.1f (most for one query %d), ranges scanned by the wave: %d in all" % (n, q[1] / n, q[2] / n, q[7], q[3] / n, q[4] / n, q[6], q[5]))
+    print("lightcam queries %d | per query: descent nodes %.1f, cells inside reached nodes %.1f, whole-cell sums %.1f, "
+          "points tested %.1f, ranges scanned by the wave: %d in all" % (n, q[1] / n, q[2] / n, q[3] / n, q[4] / n, q[5]))
 t = list(buf[32:40])
 if t[0]:
     w = t[0]
-    print("lightcam waves %d | per wave: %.0f ticks (100 MHz clock) in the query, %.0f of them in %.1f cooperative phases, slowest lane %.1f trips | "
-          "longest wave %d ticks, %d trips" % (w, t[1] / w, t[2] / w, t[4] / w, t[3] / w, t[5], t[6]))
+    print("lightcam waves %d | per wave: %.0f ticks (100 MHz clock) in its 64 queries, %.0f of them in %.1f cooperative phases, %.1f trips "
+          "with %.1f of 64 lanes holding a cell | longest wave %d ticks, %d trips" % (w, t[1] / w, t[2] / w, t[4] / w, t[3] / w, q[6] / max(t[3], 1), t[5], t[6]))
 if json_out:
     import json
     with open(json_out[0], "w") as f:
