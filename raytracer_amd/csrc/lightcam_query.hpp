@@ -92,7 +92,7 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
     }
 #ifdef RT_COUNT
     unsigned long long c_desc = 0, c_term = 0, c_sum = 0, c_pts = 0, c_coop = 0, c_cooppts = 0;
-    unsigned long long t_iters = 0, t_coop = 0, t_phases = 0, t_fill = 0;
+    unsigned long long t_iters = 0, t_coop = 0, t_phases = 0, t_fill = 0, t_pool = 0;
     const unsigned long long t_begin = wall_clock64();
 #define LCC(x) (x)
 #else
@@ -122,10 +122,18 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
     }
     while (nE + nT > 0) {
         LCC(++t_iters);
-        // a full trip of cells to sum if there is one; otherwise cells to expand, which bring more of both kinds
-        const bool sum_trip = nT >= 64 || nE == 0;
+        LCC(t_pool = (unsigned long long)(nE + nT) > t_pool ? (unsigned long long)(nE + nT) : t_pool);
+        // A full trip of cells to sum if there is one; otherwise cells to expand, which bring more of both kinds.  A cell
+        // taken frees one place and may need eight: a trip takes no more cells than the room in the pool allows (with 64
+        // places kept back from the expanding trips, so that the summing ones, which drain the pool, can always run), and
+        // a nearly full pool slows a wave down instead of losing cells.
+        const int room = LC_POOL - nE - nT;
+        const int cap_e = room - 64 >= 7 * 64 ? 64 : (room - 64 < 7 ? 0 : (room - 64) / 7);
+        const int cap_t = room >= 7 * 64 ? 64 : (room < 7 ? 1 : room / 7);
+        const bool sum_trip = nT > 0 && (nT >= 64 || nE == 0 || cap_e == 0);
         const int avail = sum_trip ? nT : nE;
-        const int take = avail < 64 ? avail : 64;
+        const int cap = sum_trip ? cap_t : (cap_e > 0 ? cap_e : 1);
+        const int take = avail < cap ? avail : cap;
         const bool have = lane < take;
         LCC(t_fill += (unsigned long long)take);
         const int at = !have ? 0 : (sum_trip ? LC_POOL - nT + lane : nE - 1 - lane);
@@ -316,6 +324,7 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
             atomicMax(&g_walk_counts[37], wall_clock64() - t_begin);
             atomicMax(&g_walk_counts[38], t_iters);
             atomicAdd(&g_walk_counts[30], t_fill);
+            atomicMax(&g_walk_counts[31], t_pool);
         }
     }
     {
