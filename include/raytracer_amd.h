@@ -213,7 +213,9 @@ int rt_noalloc_scratch_bytes(size_t *bytes);
  * "verbose", "queue_growth" (1..32); "pair", "overlap", "fused", "local" (1 forces, 0 forbids, -1 leaves to the frame's
  * size: paired passes, passes on two streams, the lane-per-sample kernel, the self-contained blocks), "local_threads"
  * (256, 512, 1024), "units" (0: the primary pass keeps fixed shares per block), "lightcam_host" (1: light-camera trees
- * built on the host); and for the next rt_upload_scene "leaf_max" (1..4), "split_budget" (percent). */
+ * built on the host), "lightcam_pool" (128..1536: places used of the pool of pending cells that a wave's 64 density
+ * queries share; a full pool slows the pass down, it loses nothing); and for the next rt_upload_scene "leaf_max"
+ * (1..4), "split_budget" (percent). */
 int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value);
 
 /* ---- several GPUs of one node ----

@@ -62,7 +62,8 @@ DEV void lc_total_add(LcWaveLds &W, int own, double v)
 }
 
 // Every lane of the wave calls it together; `active` lanes hold a query.
-DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool active, uint32_t *overflow)
+// `pool_cap` (64 < pool_cap <= LC_POOL) is how much of the pool is used: smaller values only exist to exercise a full pool.
+DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool active, uint32_t *overflow, int pool_cap)
 {
     __shared__ LcWaveLds s_lc[LC_BLOCK / 64];
     LcWaveLds &W = s_lc[threadIdx.x >> 6];
@@ -107,14 +108,14 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
         const unsigned long long mt = __ballot(pt), me = (ALSO_EXPAND) ? __ballot(pe) : 0ull;         \
         if (mt) {                                                                                     \
             const int cnt = __popcll(mt);                                                             \
-            if (nE + nT + cnt <= LC_POOL) {                                                           \
-                if (pt) { const int s = LC_POOL - 1 - (nT + __popcll(mt & below)); W.code[s] = push[c]; W.owner[s] = (unsigned char)own; } \
+            if (nE + nT + cnt <= pool_cap) {                                                           \
+                if (pt) { const int s = pool_cap - 1 - (nT + __popcll(mt & below)); W.code[s] = push[c]; W.owner[s] = (unsigned char)own; } \
                 nT += cnt;                                                                            \
             } else *overflow = 1u;                                                                    \
         }                                                                                             \
         if (me) {                                                                                     \
             const int cnt = __popcll(me);                                                             \
-            if (nE + nT + cnt <= LC_POOL) {                                                           \
+            if (nE + nT + cnt <= pool_cap) {                                                           \
                 if (pe) { const int s = nE + __popcll(me & below); W.code[s] = push[c]; W.owner[s] = (unsigned char)own; } \
                 nE += cnt;                                                                            \
             } else *overflow = 1u;                                                                    \
@@ -127,7 +128,7 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
         // taken frees one place and may need eight: a trip takes no more cells than the room in the pool allows (with 64
         // places kept back from the expanding trips, so that the summing ones, which drain the pool, can always run), and
         // a nearly full pool slows a wave down instead of losing cells.
-        const int room = LC_POOL - nE - nT;
+        const int room = pool_cap - nE - nT;
         const int cap_e = room - 64 >= 7 * 64 ? 64 : (room - 64 < 7 ? 0 : (room - 64) / 7);
         const int cap_t = room >= 7 * 64 ? 64 : (room < 7 ? 1 : room / 7);
         const bool sum_trip = nT > 0 && (nT >= 64 || nE == 0 || cap_e == 0);
@@ -136,7 +137,7 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
         const int take = avail < cap ? avail : cap;
         const bool have = lane < take;
         LCC(t_fill += (unsigned long long)take);
-        const int at = !have ? 0 : (sum_trip ? LC_POOL - nT + lane : nE - 1 - lane);
+        const int at = !have ? 0 : (sum_trip ? pool_cap - nT + lane : nE - 1 - lane);
         const int code = W.code[at];
         const int own = (int)W.owner[at];
         if (sum_trip) nT -= take; else nE -= take;
@@ -341,7 +342,7 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
     const double expected = (my_maxDist * my_maxDist) / (cam.spw * cam.spw);
     return total / expected;
 }
-DEV double lc_calc_intensity_wave(const DevLightCam *table, int cam_index, d3 pos, bool active, uint32_t *overflow)
+DEV double lc_calc_intensity_wave(const DevLightCam *table, int cam_index, d3 pos, bool active, uint32_t *overflow, int pool_cap)
 {
-    return lc_query_wave(table, cam_index, pos, active, overflow);
+    return lc_query_wave(table, cam_index, pos, active, overflow, pool_cap);
 }

@@ -954,6 +954,7 @@ struct LightcamQueues {
     const uint32_t *counts;
     uint32_t *overflow;          // the frame's "incomplete" word
     uint32_t *next_chunk;        // chunks handed out so far (zero at launch)
+    int32_t pool_cap;            // places of a wave's pool of pending cells that are used (LC_POOL)
 };
 #ifndef LC_MIN_WAVES
 #define LC_MIN_WAVES 4
@@ -990,7 +991,7 @@ __global__ __launch_bounds__(LC_BLOCK, LC_MIN_WAVES) void k_lightcam(FrameParams
         bool lit = false;
         d3 local = mk3(0, 0, 0);
         const d3 Pt = ld3(hr->P);
-        const double kfac = lc_calc_intensity_wave(P.S.lc_table, active ? hr->cam : 0, Pt, active, L.overflow);
+        const double kfac = lc_calc_intensity_wave(P.S.lc_table, active ? hr->cam : 0, Pt, active, L.overflow, L.pool_cap);
         if (active) {
             const rt_light *lt = &P.S.lights[hr->light];
             if (kfac > .01) {

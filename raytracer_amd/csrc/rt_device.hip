@@ -89,6 +89,7 @@ struct DebugOptions {
     int units = 1;                  // 0: the primary pass never shares its chunks out on the device (every block keeps to a fixed share)
     int overlap = -1;               // 1: shadow passes on the second stream beside the next closest-hit pass, 0: one stream, -1: by batch size
     int pair = -1;                  // 1: shadow pass g and closest-hit pass g+1 in one launch, 0: a launch each, -1: default (paired)
+    int lightcam_pool = LC_POOL;    // places used of a wave's pool of pending cells in the light-camera density pass (128..LC_POOL)
 };
 
 // ------------------------------------------------------------------ host side
@@ -1444,6 +1445,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     L.counts = counts;
                     L.overflow = &counts[CNT_OVERFLOW];
                     L.next_chunk = &counts[CNT_LCWORK];
+                    L.pool_cap = ctx->dbg.lightcam_pool;
                     hipLaunchKernelGGL(k_lightcam, dim3((unsigned)lightcam_blocks), dim3(LC_BLOCK), 0, st, P, L);
                 }
                 hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, counts, B.totals, P.S.n_lights);
@@ -1615,6 +1617,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 L.counts = counts;
                 L.overflow = &counts[CNT_OVERFLOW];
                 L.next_chunk = &counts[CNT_LCWORK];
+                L.pool_cap = ctx->dbg.lightcam_pool;
                 hipLaunchKernelGGL(k_lightcam, dim3((unsigned)lightcam_blocks), dim3(LC_BLOCK), 0, sb, P, L);
             }
             hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, sb, counts, B.totals, P.S.n_lights);
@@ -1777,6 +1780,7 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "local_threads") ctx->dbg.local_threads = (value == 256 || value == 512) ? (int)value : 1024;
     else if (n == "overlap") ctx->dbg.overlap = (int)value;
     else if (n == "pair") ctx->dbg.pair = (int)value;
+    else if (n == "lightcam_pool") ctx->dbg.lightcam_pool = value < 128 ? 128 : (value > LC_POOL ? LC_POOL : (int)value);
     else if (n == "queue_growth") ctx->growth = value < 1 ? 1 : (value > 32 ? 32 : (int)value);
     else return fail(RT_ERR_INVALID, "rt_debug_set_option: unknown option '" + n + "'");
     return RT_OK;

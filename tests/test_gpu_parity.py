@@ -153,6 +153,24 @@ def test_light_camera_scenes(gpu, oracle_frame, scene):
     assert np.array_equal(fast["rgb_u8"], g["rgb_u8"])
 
 
+def test_density_queries_with_a_full_pool(gpu, oracle_frame):
+    """A wave's 64 density queries share one pool of cells still to be visited (LightCam.h:121-203 is a recursion per
+    query).  With a tenth of the pool the waves run into its limit all the time: trips then take fewer cells, and the
+    frame is the same, with no overflow reported."""
+    s = load_scene(gpu, "glass")
+    cam = s.camera(300, 300)
+    full = gpu.render(cam)
+    try:
+        gpu.set_option("lightcam_pool", 160)
+        tight = gpu.render(cam)
+    finally:
+        gpu.set_option("lightcam_pool", 1 << 20)
+    o = oracle_frame("glass", res=(300, 300))
+    assert_frames_match(tight, o, tol=1e-6)
+    assert np.array_equal(tight["rgb_u8"], full["rgb_u8"])
+    assert tight["stats"]["closest_rays"] == full["stats"]["closest_rays"]
+
+
 def test_supersampling_and_depth_of_field(gpu, oracle_frame):
     """-s 2 -a 0.3 with the counter-based jitter (the reference's rand() stream is not reproducible)."""
     s = load_scene(gpu, "teapot-3")
