@@ -1212,7 +1212,10 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const int rounds = ctx->dbg.rounds > 0 ? ctx->dbg.rounds : 2;        // rounds of resident blocks a queued pass is cut into
     int max_blocks = ctx->cu_count * rounds * blocks_per_cu;
     const int max_blocks_256 = ctx->cu_count * 8;                        // the same for kernels with 256-thread blocks
-    const int lightcam_blocks = ctx->cu_count * 16 * 64 / LC_BLOCK;      // sixteen waves of density queries per compute unit
+#ifndef LC_GRID_WAVES
+#define LC_GRID_WAVES 16
+#endif
+    const int lightcam_blocks = ctx->cu_count * LC_GRID_WAVES * 64 / LC_BLOCK;      // sixteen waves of density queries per compute unit
     const long long fan_out = ctx->any_transparent ? 2 : 1;
     QueuePlan QP;
     FrameBuffers B;
