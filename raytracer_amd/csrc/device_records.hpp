@@ -66,6 +66,8 @@ struct DevScene {
     int32_t lds_cam_word;                 // first LDS word of the camera's 16 doubles (u, v, w, e, d, l, t, pix_width)
     int32_t lds_ticket_word;              // LDS word from which the waves of a block draw their next chunk
     float bvh_bound;                      // largest |coordinate| of any hierarchy box
+    int32_t shade_bounded;                // every material and light coefficient is finite and below 1e100 in magnitude: a Phong
+                                          //   factor of zero then makes the whole term zero (no infinity times zero)
     // light cameras (LightCam.h): one per (transparent sphere, light) pair, index rank*n_lights+light
     const int32_t *prim_lc_rank;          // per primitive: rank among transparent spheres, or -1
     const rt_sph_rec *tsph;               // the transparent spheres, by rank, and their primitive ids: the only

@@ -344,7 +344,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
 #define SHADOW_HYBRID 2
 #define MAX_HYBRID_SPHERES 64
 // One 64-item chunk of a shadow/shading pass; the items are (hit, light) pairs, the lights of one hit in consecutive items.
-template <int MODE>
+// SKIP_DARK: lights that add nothing at a hit are not queried (below).  Taken by the kernels of small frames, where a wave
+// lasts as long as its slowest lane's walk and whole waves lie on the side of an object a light does not reach
+// (512 x 512 frames 1.5 to 5 % faster); over a large frame 8 % of the queries go, the other lanes of their waves walk on
+// all the same, and the test costs what that saves (8K frame: shadow passes 30.9 -> 31.4 ms), so k_shadow asks every light.
+template <int MODE, bool SKIP_DARK>
 DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &smap, uint32_t nl, long long chunk, int *stack, bool cull,
                       WalkCount &wc)
 {
@@ -386,8 +390,17 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
         if (order_free) {
             // no transparent sphere in the way: "occluded" is "any hit", and never "only transparent"
             const double d2 = dot3(rd, rd);
-            occluded = false;
-            if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
+            // A light that adds exactly nothing at this hit needs no answer (the reference asks, and multiplies the
+            // answer's consequence by zero): such an item counts as shadowed.
+            bool dark = false;
+            if (SKIP_DARK && P.S.shade_bounded && fabs(weight) < 1e300) {
+                const void *nsrc = hit_flat ? (const void *)&P.S.prim_n23[(size_t)hit_prim * 6] : (const void *)hr->n;
+                const rec_v2d g2 = rec_load(hr, 2), n0 = rec_load(nsrc, 0), n1 = rec_load(nsrc, 1), n2 = rec_load(nsrc, 2);
+                const rt_material m = load_material(P.S, hit_flat ? P.S.prim_material[hit_prim] : hr->mat, true);
+                dark = light_adds_nothing(m.Kd, m.Ks, m.Shine, mk3(n0.x, n0.y, n1.x), mk3(n1.y, n2.x, n2.y), mk3(h1.y, g2.x, g2.y), rd);
+            }
+            occluded = dark;
+            if (!dark && root_gate(P.S, Pt, rd, d2, 10000000.0)) {
                 const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
                 WC_ADD(wc, rays);
                 occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc) ||
@@ -465,7 +478,7 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
     const bool cull = P.cull_shadow != 0;
     WalkCount wc{};
     for (long long chunk = next_chunk(P.S); chunk < (long long)smap.total; chunk = next_chunk(P.S)) {
-        shadow_chunk<MODE>(P, Q, smap, nl, chunk, stack, cull, wc);
+        shadow_chunk<MODE, false>(P, Q, smap, nl, chunk, stack, cull, wc);
     }
     STAMP(9);
 #ifdef RT_COUNT
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_pair(FramePar
     const bool cull_s = P.cull_shadow != 0, cull_c = P.cull_closest != 0;
     WalkCount wc{};
     for (long long chunk = next_chunk(P.S); chunk < total; chunk = next_chunk(P.S)) {
-        if (chunk < n_s) shadow_chunk<MODE>(P, Qs, sm_s, nl, chunk, stack, cull_s, wc);
+        if (chunk < n_s) shadow_chunk<MODE, true>(P, Qs, sm_s, nl, chunk, stack, cull_s, wc);
         else closest_chunk<false, BVHC>(P, Qc, sm_c, chunk - n_s, lane, stack, cull_c, wc, blockIdx.x & (N_SHARDS - 1));
     }
 #ifdef RT_COUNT
@@ -535,6 +548,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_pair(FramePar
 // frame's sharded queues).
 struct LocalPlan {
     uint32_t chunks_per_block;   // primary chunks of a block
+    uint32_t rotate;             // the blocks' shares move on by this many places from one round of primary chunks to the next
     uint32_t ray_cap, hit_cap;   // records of one block's ray list / hit list of one generation
     int32_t lds_counts_word;     // first LDS word of the block's CNT_WORDS counters, followed by 32 words of bookkeeping and a word
                                  // per 64 records of the ray lists of generations 1..5
@@ -550,8 +564,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
     const long long n_chunks = Q0.chunk_end - Q0.chunk_begin;
     // a block's primary chunks lie a grid apart, all over the frame: every block then gets its share of the parts of
     // the image where the trees are deep
+    // (and not one column of the image: the k-th chunk of block b is chunk k * grid + (b + k * rotate) mod grid, so with
+    // a grid that is a multiple of the blocks per image row a block still visits a different column every time)
     if ((long long)blockIdx.x >= n_chunks) return;
-    const uint32_t my_chunks = (uint32_t)((n_chunks - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    const uint32_t full_rounds = (uint32_t)(n_chunks / gridDim.x), last_round = (uint32_t)(n_chunks - (long long)full_rounds * gridDim.x);
+    const uint32_t my_chunks = full_rounds + ((blockIdx.x + full_rounds * L.rotate) % gridDim.x < last_round ? 1u : 0u);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(&s_lds[L.lds_counts_word]);
     for (int i = (int)threadIdx.x; i < CNT_WORDS + 32 + 5 * (int)(L.ray_cap >> 6); i += (int)blockDim.x) cnt[i] = 0u;
     if (threadIdx.x == 0) camera_to_lds(P);
@@ -634,7 +651,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
             __threadfence_block();                // what the chunk reads was written before it was announced
             QueueSet Qc = queue_set(cg);
             Qc.commit = cg < 5 ? const_cast<uint32_t *>(written) + cg * pieces : nullptr;
-            if (cg == 0) closest_chunk<true, true>(P, Qc, none, (long long)blockIdx.x + (long long)ct * gridDim.x, lane, stack, cull_c, wc, 0u);
+            if (cg == 0) closest_chunk<true, true>(P, Qc, none, (long long)((blockIdx.x + ct * L.rotate) % gridDim.x) + (long long)ct * gridDim.x, lane, stack, cull_c, wc, 0u);
             else closest_chunk<false, true>(P, Qc, local_map(cn, L.ray_cap, 1u), (long long)ct, lane, stack, cull_c, wc, 0u);
             __threadfence_block();                // the records are written before the chunk counts as done
             if (lane == 0) atomicAdd(&sync_rw[6 + cg], 1u);
@@ -648,7 +665,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
             const uint32_t t = take(12 + gg, sm_s.total);
             if (t != ~0u) {
                 const QueueSet Qs = queue_set(gg);
-                shadow_chunk<MODE>(P, Qs, sm_s, nl, (long long)t, stack, cull_s, wc);
+                shadow_chunk<MODE, true>(P, Qs, sm_s, nl, (long long)t, stack, cull_s, wc);
                 shaded = true;
             }
         }

@@ -85,6 +85,8 @@ struct DebugOptions {
     int lightcam_host = 0;          // 1: the light cameras' point octrees are built by the host builder (lightcam_build.cpp)
     int fused = -1;                 // 1: always the one-launch kernel, 0: never, -1: by frame size
     int local_threads = 1024;       // block size of the block-local kernel (256, 512 or 1024)
+    int local_min_chunks = 0;       // primary chunks a block of the block-local kernel gets at least (0: four)
+    int local_rotate = -1;          // places a block's share of the primary chunks moves on per round (-1: chosen from the image width)
     int local = -1;                 // 1: always the block-local one-launch kernel where it applies, 0: never, -1: by frame size
     int units = 1;                  // 0: the primary pass never shares its chunks out on the device (every block keeps to a fixed share)
     int overlap = -1;               // 1: shadow passes on the second stream beside the next closest-hit pass, 0: one stream, -1: by batch size
@@ -476,6 +478,19 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
         if ((rc = upload(ctx, tsph_prim.data(), tsph_prim.size(), &D.tsph_prim)) != RT_OK) return rc;
         D.n_tsph = static_cast<int32_t>(tsph.size());
         ctx->h_lights.assign(s->lights, s->lights + s->n_lights);
+    }
+    {
+        auto bounded = [](double x) { return std::fabs(x) < 1e100; };      // false for NaN and infinities too
+        bool ok = true;
+        for (int32_t i = 0; i < s->n_materials; ++i) {
+            const rt_material &m = s->materials[i];
+            ok = ok && bounded(m.r) && bounded(m.g) && bounded(m.b) && bounded(m.Kd) && bounded(m.Ks) && bounded(m.Shine);
+        }
+        for (int32_t i = 0; i < s->n_lights; ++i) {
+            const rt_light &l = s->lights[i];
+            ok = ok && bounded(l.intensity) && bounded(l.color[0]) && bounded(l.color[1]) && bounded(l.color[2]);
+        }
+        D.shade_bounded = ok ? 1 : 0;
     }
     D.lc_table = nullptr;
     D.lc_needed = nullptr;
@@ -1143,10 +1158,13 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     size_t local_lds = 0;
     bool local_fits = want_local;
     if (want_local) {
-        const long long slots = (long long)waves_per_block * ctx->cu_count * blocks_per_cu;
-        const long long k = (n_chunks + slots - 1) / slots;
-        local_cpb = waves_per_block * k;
-        local_grid = (n_chunks + local_cpb - 1) / local_cpb;
+        // every compute unit gets a block as soon as there are `min_chunks` primary chunks for each (a frame of 4800 chunks
+        // cut into runs of whole rounds of waves was 150 blocks of 32 chunks on a chip of 256 compute units)
+        const long long resident = (long long)ctx->cu_count * blocks_per_cu;
+        const long long min_chunks = ctx->dbg.local_min_chunks > 0 ? ctx->dbg.local_min_chunks : 4;
+        local_grid = (n_chunks + min_chunks - 1) / min_chunks;
+        if (local_grid > resident) local_grid = resident;
+        local_cpb = (n_chunks + local_grid - 1) / local_grid;
         local_cap = local_cpb * 64 * (ctx->any_transparent ? (long long)ctx->growth : 1ll);
         local_lds = (size_t)(CNT_WORDS + 32 + 5 * (local_cap / 64)) * sizeof(uint32_t);
         if (local_lds > 24 * 1024) local_fits = false;       // (deep queues after overflows: the launch-per-pass path takes over)
@@ -1234,6 +1252,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     LocalPlan LP{};
     if (use_local) {
         LP.chunks_per_block = (uint32_t)local_cpb;
+        // about 0.38 of an image row of 8x8-pixel blocks, odd: a block's successive chunks then lie in columns spread over the
+        // whole width, whatever the grid's relation to the row length is
+        LP.rotate = ctx->dbg.local_rotate >= 0 ? (uint32_t)ctx->dbg.local_rotate : ((uint32_t)(P.blocks_x * 0.382 + 0.5) | 1u);
         const size_t bytes = (size_t)(local_grid * local_cap) * (7 * sizeof(RayRec) + 6 * (all_flat ? 64 : sizeof(HitRec)));
         if (bytes > ctx->queue_budget) use_local = false;        // the launch-per-pass path cuts the frame into batches
     }
@@ -1781,6 +1802,8 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "units") ctx->dbg.units = (int)value;
     else if (n == "local") ctx->dbg.local = (int)value;
     else if (n == "local_threads") ctx->dbg.local_threads = (value == 256 || value == 512) ? (int)value : 1024;
+    else if (n == "local_min_chunks") ctx->dbg.local_min_chunks = value < 0 ? 0 : (int)(value & 0xffff);
+    else if (n == "local_rotate") ctx->dbg.local_rotate = value < 0 ? -1 : (int)(value & 0xffff);
     else if (n == "overlap") ctx->dbg.overlap = (int)value;
     else if (n == "pair") ctx->dbg.pair = (int)value;
     else if (n == "lightcam_pool") ctx->dbg.lightcam_pool = value < 128 ? 128 : (value > LC_POOL ? LC_POOL : (int)value);

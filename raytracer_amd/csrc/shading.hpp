@@ -86,6 +86,22 @@ DEV d3 phong_terms(const rt_material &m, d3 normal, d3 nn, d3 v, const rt_light 
     return local;
 }
 
+// True when phong_terms() of this light at this hit is zero in every component for sure, whatever the factor: the
+// diffuse term is `coefficients * max(rd.normal, 0)` and the specular term `coefficients * pow(max(rdir.v, 0), Shine)`
+// (Solid.h:133,166-167), so with bounded coefficients a light from behind the shading normal whose mirror direction
+// points away from the viewer adds +-0 to the colour, seen or not (Camera.h:465-476).  The mirror direction is judged
+// before its normalisation with a margin far beyond the rounding of the normalised form: |raw| <= 3 and |v| <= 1, so
+// raw.v < -1e-6 puts the normalised product below -3e-7 where its rounding error is about 1e-15.
+DEV bool light_adds_nothing(double Kd, double Ks, double Shine, d3 normal, d3 nn, d3 v, d3 rd)
+{
+    const double a = dot3(rd, normal);
+    if (!(a < 0.0 || (Kd == 0.0 && fabs(a) < 1e100))) return false;
+    if (!(Ks > 0)) return true;
+    if (!(Shine > 0.0)) return false;
+    const d3 raw = add3(neg3(rd), scale3(2.0 * dot3(rd, nn), nn));
+    return dot3(raw, v) < -1e-6 && dot3(nn, nn) < 1.001 && dot3(v, v) < 1.001;
+}
+
 // Counter-based stand-in for the reference's shared rand() % 1000 / 1000 (Camera.h:99-103).
 DEV uint32_t hash_rng(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
 {

@@ -131,6 +131,34 @@ def test_non_finite_and_far_away_coordinates(gpu, tmp_path):
     assert (g["hit_id"] >= 0).any()
 
 
+def test_lights_that_add_nothing_are_not_queried(gpu, tmp_path):
+    # The kernels of small frames skip the shadow query of a light whose Phong terms at the hit are zero for sure (behind the
+    # shading normal and mirrored away from the viewer).  Cases where "behind" is not "nothing": Shine 0 (pow(0, 0) is 1),
+    # Kd 0, Ks 0, a coefficient too large to rule out infinity times zero, lights on both sides of thin geometry.
+    lights = "l 5 5 9\nl -6 -3 -7\nl 0.2 0.1 -9\nl -8 6 0.5\n"
+    shapes = ("p 3\n-3 -3 {z}\n3 -3 {z}\n0 3 {z}\ns 1.2 0.3 {zs} 0.6\ns -1.1 -0.4 {zs} 0.5\np 3\n-1 2 {z}\n-2.5 2.5 {zt}\n-1.5 3.5 {zt}\n")
+    for name, mat in (("plain", "f 0.8 0.5 0.3 0.7 0.4 12 0 1"), ("shine0", "f 0.8 0.5 0.3 0.7 0.4 0 0 1"), ("kd0", "f 0.8 0.5 0.3 0 0.6 8 0 1"),
+                      ("ks0", "f 0.8 0.5 0.3 0.9 0 8 0 1"), ("black", "f 0.8 0.5 0.3 0 0 8 0 1"), ("huge", "f 1e200 0.5 0.3 1e150 0.4 12 0 1"),
+                      ("mirror", "f 0.8 0.5 0.3 0.3 0.9 30 0 1")):
+        body = lights + mat + "\n" + shapes.format(z="0", zs="0.8", zt="1.5") + "f 0.2 0.6 0.9 0.6 0.5 3 0 1\n" + shapes.format(z="-2", zs="-1.2", zt="-3")
+        path = write_scene(tmp_path, "dark_" + name, body, res="96 80")
+        frames = []
+        for opts in ({"local": 1, "fused": 0}, {"local": 0, "fused": 0, "pair": 1}, {"local": 0, "fused": 0, "pair": 0}):
+            for k, v in opts.items():
+                gpu.set_option(k, v)
+            try:
+                g, ref = both(gpu, path)
+            finally:
+                for k in opts:
+                    gpu.set_option(k, -1)
+            if name == "huge":      # the colour overflows on both sides: the bytes and the ray counts are what can be compared
+                assert np.array_equal(g["rgb_u8"], ref["rgb_u8"]) and g["stats"]["shadow_rays"] == ref["counters"]["shadow_rays"]
+            else:
+                check(g, ref)
+            frames.append(g)
+        assert np.array_equal(frames[0]["rgb_u8"], frames[2]["rgb_u8"]) and np.array_equal(frames[1]["rgb_u8"], frames[2]["rgb_u8"])
+
+
 def test_more_lights_and_materials_than_the_on_chip_tables_hold(gpu, tmp_path):
     # 18 lights and 70 materials: entries beyond the first 16 / 64 are read from memory instead of LDS
     rng = np.random.default_rng(5)

@@ -348,6 +348,35 @@ def test_self_contained_blocks_are_repeatable(gpu, scene, res, n):
         gpu.set_option("fused", -1)
 
 
+@pytest.mark.parametrize("scene,res", [("balls", (200, 136)), ("teapot-3", (333, 250)), ("refract", (640, 480))])
+def test_self_contained_blocks_share_out_any_frame(gpu, scene, res):
+    """The plan of the self-contained blocks (how many blocks, how far a block's share of the primary chunks moves on from
+    round to round) decides who renders what, never what is rendered: frames whose chunk count is no multiple of the grid,
+    with every rotation and minimum share, against the launch-per-pass frame."""
+    s = load_scene(gpu, scene)
+    cam = s.camera(*res)
+    gpu.set_option("fused", 0)
+    try:
+        gpu.set_option("local", 0)
+        ref = gpu.render(cam, flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+        gpu.set_option("local", 1)
+        for rotate, min_chunks in ((-1, 0), (0, 0), (1, 1), (7, 3), (255, 16), (1000, 64), (31, 5)):
+            gpu.set_option("local_rotate", rotate)
+            gpu.set_option("local_min_chunks", min_chunks)
+            f = gpu.render(cam, flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+            assert f["stats"]["queue_overflow"] == 0
+            assert f["stats"]["rays_per_generation"] == ref["stats"]["rays_per_generation"], (rotate, min_chunks)
+            assert f["stats"]["shadow_rays"] == ref["stats"]["shadow_rays"], (rotate, min_chunks)
+            assert np.array_equal(f["hit_id"], ref["hit_id"]), (rotate, min_chunks)
+            assert np.array_equal(f["rgb_u8"], ref["rgb_u8"]), (rotate, min_chunks)
+            assert np.abs(f["rgb_f64"] - ref["rgb_f64"]).max() <= 1e-9, (rotate, min_chunks)
+    finally:
+        gpu.set_option("local", -1)
+        gpu.set_option("local_rotate", -1)
+        gpu.set_option("local_min_chunks", 0)
+        gpu.set_option("fused", -1)
+
+
 def test_primary_pass_in_units_drawn_while_it_runs(gpu, oracle_frame):
     """A primary pass with many chunks per wave hands its chunks out in units while it runs (a counter in memory, a
     permuted order, records sharded by unit) instead of giving every block a fixed share: the same frame and ray counts
