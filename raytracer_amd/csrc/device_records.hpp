@@ -156,6 +156,8 @@ struct QueueSet {
                                      // block of 8x8 pixels (chunk_begin is a multiple of N*N)
     int64_t block_row0;              // PRIMARY only: row and column, in 8x8-pixel blocks, of the batch's first block
     int32_t block_col0;
+    uint32_t *defer_counts;          // k_local only: the shard counters of the deferred queue (the frame's, in memory, where the
+                                     //   block's other counters are in LDS); null: counts + CNT_DEFER(generation)
     uint32_t *commit;                // k_local only: per 64 records of rays_out, how many have been written (a word in LDS each)
     unsigned long long *totals;      // the one-launch kernel only: the frame's ray statistics (16 words)
 };

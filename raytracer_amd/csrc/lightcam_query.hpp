@@ -93,7 +93,7 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
     }
 #ifdef RT_COUNT
     unsigned long long c_desc = 0, c_term = 0, c_sum = 0, c_pts = 0, c_coop = 0, c_cooppts = 0;
-    unsigned long long t_iters = 0, t_coop = 0, t_phases = 0, t_fill = 0, t_pool = 0;
+    unsigned long long t_iters = 0, t_coop = 0, t_phases = 0, t_fill = 0, t_pool = 0, t_exp = 0, n_exp = 0, t_sum = 0, n_sum = 0;
     const unsigned long long t_begin = wall_clock64();
 #define LCC(x) (x)
 #else
@@ -137,6 +137,9 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
         const int take = avail < cap ? avail : cap;
         const bool have = lane < take;
         LCC(t_fill += (unsigned long long)take);
+#ifdef RT_COUNT
+        const unsigned long long t_trip = wall_clock64();
+#endif
         const int at = !have ? 0 : (sum_trip ? pool_cap - nT + lane : nE - 1 - lane);
         const int code = W.code[at];
         const int own = (int)W.owner[at];
@@ -212,6 +215,7 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
                 }
             }
             LC_PUSH_ALL(true)
+            LCC(t_exp += wall_clock64() - t_trip); LCC(++n_exp);
             continue;
         }
         // sqrt is monotonic and correctly rounded: |v| < maxDist is decided on the squared length
@@ -279,6 +283,7 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
             }
         }
         LC_PUSH_ALL(false)
+        LCC(t_sum += wall_clock64() - t_trip); LCC(++n_sum);
         unsigned long long mask = __ballot(pending);
         if (mask) {
 #ifdef RT_COUNT
@@ -326,6 +331,8 @@ DEV double lc_query_wave(const DevLightCam *table, int cam_index, d3 pos, bool a
             atomicMax(&g_walk_counts[38], t_iters);
             atomicAdd(&g_walk_counts[30], t_fill);
             atomicMax(&g_walk_counts[31], t_pool);
+            atomicAdd(&g_walk_counts[41], t_exp); atomicAdd(&g_walk_counts[42], n_exp);      // ticks and number of the trips of either kind
+            atomicAdd(&g_walk_counts[43], t_sum); atomicAdd(&g_walk_counts[44], n_sum);
         }
     }
     {

@@ -439,7 +439,8 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
     if (MODE != SHADOW_BVH && P.S.lc_table) {
         bool ok;
         const bool want = defer_cam >= 0;
-        const uint32_t slot = wave_reserve(want, &Q.counts[CNT_DEFER(Q.generation)], Q.defer_shard_cap, &Q.counts[CNT_OVERFLOW + 1], &ok);
+        const uint32_t slot = wave_reserve(want, Q.defer_counts ? Q.defer_counts : &Q.counts[CNT_DEFER(Q.generation)], Q.defer_shard_cap,
+                                           &Q.counts[CNT_OVERFLOW + 1], &ok);
         if (ok) {
             HitRec *dr = &Q.deferred[slot];
             *dr = *hr;
@@ -544,8 +545,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_pair(FramePar
 // the block's barrier only.  A slow wave then holds up the fifteen other waves of its block for one pass, not the chip,
 // and blocks drift apart freely.  Rays are still regrouped into full waves, per block.  At the end the block adds its
 // counters to the frame's (shard 0), for the statistics and the overflow report.
-// Only for scenes whose shadow queries take the hierarchies (no deferred light-camera queries, which go through the
-// frame's sharded queues).
+// For scenes whose shadow queries take the hierarchies, all of them or (with a few transparent spheres) ray by ray; the
+// light-camera evaluations such a query postpones go to the frame's sharded queue in memory, all generations in one
+// list, and are answered by the launch after this one.
 struct LocalPlan {
     uint32_t chunks_per_block;   // primary chunks of a block
     uint32_t rotate;             // the blocks' shares move on by this many places from one round of primary chunks to the next
@@ -555,6 +557,8 @@ struct LocalPlan {
     RayRec *rays;                // one slice per generation (1..6) and block
     HitRec *hits;                // one slice per generation and block
     uint32_t *frame_counts;      // the frame's counters
+    HitRec *deferred;            // the frame's queue of postponed light-camera evaluations (all generations in one), or null
+    uint32_t defer_shard_cap;
 };
 template <int MODE>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FrameParams P, QueueSet Q0, LocalPlan L)
@@ -590,6 +594,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
         Q.hit_shard_cap = L.hit_cap;
         Q.generation = g;
         Q.unit_chunks = 0;
+        Q.deferred = L.deferred;
+        Q.defer_shard_cap = L.defer_shard_cap;
+        Q.defer_counts = L.deferred ? &L.frame_counts[CNT_DEFER(0)] : nullptr;
         return Q;
     };
     auto local_map = [&](uint32_t records, uint32_t cap, uint32_t per_record) {

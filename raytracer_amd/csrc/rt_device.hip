@@ -72,7 +72,7 @@ void *g_scratch_ptr[RT_MAX_DEVICES] = {};       // per device: address of that d
 #define RT_DEFAULT_QUEUE_BUDGET ((size_t)32 << 30)
 // Frames of at most this many samples run as one launch per batch (k_fused) instead of the wavefront pipeline.
 #define RT_FUSED_MAX_SAMPLES (1ll << 20)
-#define RT_LOCAL_MAX_SAMPLES (1ll << 21)     // frames up to this many samples run as one launch of self-contained blocks (k_local)
+#define RT_LOCAL_MAX_SAMPLES (1ll << 22)     // frames up to this many samples run as one launch of self-contained blocks (k_local)
 
 // Experiment switches (rt_debug_set_option); the defaults are what the product runs.
 struct DebugOptions {
@@ -240,7 +240,7 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
                                  (const void *)k_shadow_hybrid,
                                  (const void *)k_pair<true, SHADOW_BVH>, (const void *)k_pair<true, SHADOW_HYBRID>,
                                  (const void *)k_pair<true, SHADOW_EXACT>, (const void *)k_pair<false, SHADOW_EXACT>,
-                                 (const void *)k_local<SHADOW_BVH>,
+                                 (const void *)k_local<SHADOW_BVH>, (const void *)k_local<SHADOW_HYBRID>,
                                  (const void *)k_fused<true, SHADOW_BVH>, (const void *)k_fused<true, SHADOW_HYBRID>,
                                  (const void *)k_fused<true, SHADOW_EXACT>, (const void *)k_fused<false, SHADOW_EXACT>};
         for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
@@ -1145,8 +1145,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                                                     !ctx->any_secondary && !(o->flags & RT_FLAG_KEEP_ZERO_WEIGHT)));
     // The block-local one-launch kernel (k_local) takes frames of one batch that are too small to fill the chip pass by
     // pass, in scenes whose trees go on after the first hit and whose shadow queries take the hierarchies.
-    const bool want_local = !noalloc && !use_fused && local_rows > 0 && may_cull && ctx->accel_usable && !ctx->any_transparent_sphere &&
-                            batch_chunks >= n_chunks &&
+    const bool want_local = !noalloc && !use_fused && local_rows > 0 && may_cull && ctx->accel_usable && batch_chunks >= n_chunks &&
                             (ctx->dbg.local == 1 || (ctx->dbg.local < 0 && n_chunks * 64 <= RT_LOCAL_MAX_SAMPLES));
     int block = want_local ? ctx->dbg.local_threads : (noalloc || use_fused || batch_chunks * 64 <= (1ll << 22)) ? 256 : RT_BLOCK;
     if (!use_fused && (ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024)) block = ctx->dbg.block_threads;
@@ -1219,7 +1218,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     // every traversal kernel gets the same layout (the octree-walk variants use the tables only)
     const size_t lds_bvh = lds_stack + (size_t)(P.S.tri_cached + P.S.sph_cached) * NODE_LDS_WORDS * sizeof(int) +
                            (size_t)P.S.btri_cached * 80 + lds_tables + 128 + 32;
-    bool use_local = local_fits && bvh_closest_ok && bvh_shadow_ok;      // (and its queues within the memory budget, below)
+    bool use_local = local_fits && bvh_closest_ok && (bvh_shadow_ok || hybrid_shadow);      // (and its queues within the memory budget, below)
     const int lds_counts_word = P.S.lds_ticket_word + 8;                 // k_local: the block's own queue counters
     const size_t lds_local = lds_bvh + local_lds;
     const size_t lds_closest = lds_bvh;
@@ -1289,6 +1288,15 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         LP.hits = ctx->hits[0];
         LP.lds_counts_word = lds_counts_word;
         LP.frame_counts = ctx->counts;
+        if (use_lightcam) {
+            // postponed light-camera evaluations of all generations in one sharded list (as the lane-per-sample kernel keeps it)
+            fused_defer_cap = (n_chunks * 64 * ctx->growth * (P.S.n_lights > 0 ? P.S.n_lights : 1) + N_SHARDS - 1) / N_SHARDS;
+            if (fused_defer_cap < 1024) fused_defer_cap = 1024;
+            if ((rc = ensure(&ctx->deferred[0], &ctx->deferred_capacity[0], (size_t)(fused_defer_cap * N_SHARDS))) != RT_OK) return rc;
+            LP.deferred = ctx->deferred[0];
+            LP.defer_shard_cap = (uint32_t)fused_defer_cap;
+            B.deferred[0] = ctx->deferred[0];
+        }
         B.accum = ctx->accum;
         B.counts = ctx->counts;
         B.totals = ctx->totals;
@@ -1489,8 +1497,21 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
             if (timing && !(ev = next_event_pair(ctx->ev_closest, ctx->ev_closest_used))) return fail(RT_ERR_DEVICE, "hipEventCreate failed");
             if (ev) HIP_TRY(hipEventRecord(ev->first, st));
-            hipLaunchKernelGGL((k_local<SHADOW_BVH>), dim3((unsigned)local_grid), dim3(block), lds_local, st, P, Q, LP);
+            if (bvh_shadow_ok) hipLaunchKernelGGL((k_local<SHADOW_BVH>), dim3((unsigned)local_grid), dim3(block), lds_local, st, P, Q, LP);
+            else hipLaunchKernelGGL((k_local<SHADOW_HYBRID>), dim3((unsigned)local_grid), dim3(block), lds_local, st, P, Q, LP);
             if (ev) HIP_TRY(hipEventRecord(ev->second, st));
+            if (use_lightcam) {
+                int lrc = provide_lightcams(ctx, lc_flags, may_cull, true);
+                if (lrc != RT_OK) return lrc;
+                LightcamQueues L{};
+                L.deferred[0] = B.deferred[0];
+                L.shard_cap[0] = (uint32_t)fused_defer_cap;
+                L.counts = counts;
+                L.overflow = &counts[CNT_OVERFLOW];
+                L.next_chunk = &counts[CNT_LCWORK];
+                L.pool_cap = ctx->dbg.lightcam_pool;
+                hipLaunchKernelGGL(k_lightcam, dim3((unsigned)lightcam_blocks), dim3(LC_BLOCK), 0, st, P, L);
+            }
             ctx->pending_batches++;      // (k_finalize rolls the counters up)
             batch_no = 1;
             HIP_TRY(hipEventRecord(ctx->ev_batch[0], st));

@@ -41,6 +41,9 @@ if t[0]:
     w = t[0]
     print("lightcam waves %d | per wave: %.0f ticks (100 MHz clock) in its 64 queries, %.0f of them in %.1f cooperative phases, %.1f trips "
           "with %.1f of 64 lanes holding a cell | longest wave %d ticks, %d trips | most cells pending in a wave %d" % (w, t[1] / w, t[2] / w, t[4] / w, t[3] / w, q[6] / max(t[3], 1), t[5], t[6], q[7]))
+if t[0] and buf[42] + buf[44]:
+    print("lightcam trips: %.1f per wave judge children (%.0f ticks each), %.1f per wave sum cells (%.0f ticks each)"
+          % (buf[42] / t[0], buf[41] / max(buf[42], 1), buf[44] / t[0], buf[43] / max(buf[44], 1)))
 if json_out:
     import json
     with open(json_out[0], "w") as f:
