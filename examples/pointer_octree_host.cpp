@@ -1,7 +1,7 @@
 // A host that holds its scene the way the reference does -- primitives in a vector, the octree as nodes that point to
 // their children and list their residents -- and renders through the C ABI of include/raytracer_amd.h.
 //
-// It is the compile-tested form of the change INTEGRATION.md describes for the reference's renderMultithreaded
+// It is the compile-tested form of the change a maintainer would make to the reference's renderMultithreaded
 // (Driver.cpp:355-390): flatten the pointer octree in depth-first pre-order with skip links, fill the per-primitive
 // tables, copy the camera, call rt_render, write the image.  The classes below are this example's own stand-ins for the
 // reference's Solid / Octree<Solid*> / Camera (only the fields the flattening reads); to have a real scene to work

@@ -61,7 +61,7 @@ def test_driver_writes_the_reference_image_and_honours_its_flags(tmp_path):
 
 def test_pointer_octree_host_example(tmp_path):
     """examples/pointer_octree_host.cpp, the compile-tested form of the reference-side integration: a host that keeps a
-    pointer octree and a primitive vector, flattens them as INTEGRATION.md describes and renders through the C ABI.  Its
+    pointer octree and a primitive vector, flattens them (depth-first pre-order with skip links) and renders through the C ABI.  Its
     arrays must equal the front end's (exit code 0) and its image the command-line host's."""
     example = os.path.join(ROOT, "raytracer_amd", "bin", "pointer_octree_host")
     assert os.path.exists(example), "build it with python -m raytracer_amd.build"
