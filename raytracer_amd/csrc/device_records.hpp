@@ -122,6 +122,7 @@ struct FrameParams {
     int32_t band_rows, n_parts, part, local_rows;
     int32_t blocks_x;            // 8x8-pixel blocks per row of blocks (primary sample ordering)
     FastDiv div_spp, div_blocks_x, div_n, div_band;   // by N*N, blocks_x, N, band_rows
+    FastDiv div_lights;          // by the number of lights (at least 1)
     int32_t cull_closest, cull_shadow;
     double *accum;               // local_rows*resx*3
     int32_t *hit_id;             // local_rows*resx or null

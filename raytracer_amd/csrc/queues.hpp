@@ -76,6 +76,45 @@ DEV int shard_locate(const ShardMap &m, uint32_t c, int *shard_out, int pos_in_c
     return idx < items ? (int)idx : -1;
 }
 
+// The (hit, light) items of a shadow pass as a list of chunks in which every chunk holds ONE light: a shard's hits in
+// groups of 64, and per group one chunk for each light.  The 64 rays of a wave then all run towards the same light --
+// one bundle -- where items dealt out light by light within a hit gave every wave as many interleaved bundles as there
+// are lights.  `items` is the shard's hit count here.
+DEV ShardMap shard_map_by_light(const uint32_t *shard_counters, uint32_t shard_cap, uint32_t n_lights)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    ShardMap m;
+    uint32_t n = shard_counters[lane];
+    if (n > shard_cap) n = shard_cap;
+    m.items = n;
+    uint32_t chunks = ((n + 63u) >> 6) * n_lights;
+    uint32_t incl = chunks;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += v;
+    }
+    m.first = incl - chunks;
+    m.total = (uint32_t)__shfl((int)incl, 63);
+    if (n_lights == 0) m.items = 0;
+    return m;
+}
+// For chunk c (same in all lanes) of such a list: shard, light (the same for the whole wave), and this lane's hit index
+// inside the shard (or -1).
+DEV int shard_locate_by_light(const ShardMap &m, uint32_t c, const FastDiv &div_lights, int *shard_out, int *light_out)
+{
+    const unsigned long long le = __ballot(m.first <= c && m.items > 0);
+    const int shard = 63 - __clzll((long long)le);
+    const uint32_t first = (uint32_t)__shfl((int)m.first, shard);
+    const uint32_t hits = (uint32_t)__shfl((int)m.items, shard);
+    const uint32_t rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c - first));
+    const uint32_t group = fast_div(rel, div_lights);
+    *light_out = (int)(rel - group * div_lights.d);
+    const uint32_t idx = group * 64u + (uint32_t)(threadIdx.x & 63);
+    *shard_out = shard;
+    return idx < hits ? (int)idx : -1;
+}
+
 // Adds w*c to a pixel.  Lanes that hold the same pixel in a contiguous run of lanes are summed
 // first and the run's first lane issues the (memory-side) FP64 atomics.  `in_queue` lanes take
 // part in runs even when they contribute nothing (`valid` false), so a shadowed light does not

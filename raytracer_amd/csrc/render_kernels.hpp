@@ -343,7 +343,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
 #define SHADOW_BVH 1
 #define SHADOW_HYBRID 2
 #define MAX_HYBRID_SPHERES 64
-// One 64-item chunk of a shadow/shading pass; the items are (hit, light) pairs, the lights of one hit in consecutive items.
+// One 64-item chunk of a shadow/shading pass; the items are (hit, light) pairs, 64 consecutive hits with one light (shard_map_by_light).
 // SKIP_DARK: lights that add nothing at a hit are not queried (below).  Taken by the kernels of small frames, where a wave
 // lasts as long as its slowest lane's walk and whole waves lie on the side of an object a light does not reach
 // (512 x 512 frames 1.5 to 5 % faster); over a large frame 8 % of the queries go, the other lanes of their waves walk on
@@ -353,11 +353,10 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
                       WalkCount &wc)
 {
 #define STAMP_SEL (8 + Q.generation)
-    int shard;
-    const int item = shard_locate(smap, (uint32_t)chunk, &shard);
+    int shard, li;
+    const int item = shard_locate_by_light(smap, (uint32_t)chunk, P.div_lights, &shard, &li);      // one light per chunk
     const bool active = item >= 0;
-    const uint32_t h = active ? (uint32_t)item / nl : 0u;
-    const int li = active ? (int)((uint32_t)item - h * nl) : 0;
+    const uint32_t h = active ? (uint32_t)item : 0u;
     const HitRec *hr = (const HitRec *)((const char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + h) * Q.hit_stride);
     // head of the record: P, weight, pixel, prim, material -- four 16-byte pieces fetched together
     const rec_v2d h0 = rec_load(hr, 0), h1 = rec_load(hr, 1), h3 = rec_load(hr, 3);
@@ -470,8 +469,8 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
     const uint32_t nl = (uint32_t)P.S.n_lights;
     STAMP(0);
-    // work items are (hit, light) pairs, the lights of one hit in consecutive items
-    const ShardMap smap = shard_map(&Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, nl);
+    // work items are (hit, light) pairs: per 64 hits of a shard one chunk for each light
+    const ShardMap smap = shard_map_by_light(&Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, nl);
     if ((long long)blockIdx.x * (blockDim.x >> 6) >= (long long)smap.total) return;   // no chunk for this block
     STAMP(1);
     fill_node_cache(P.S, BVH);
@@ -517,7 +516,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_pair(FramePar
     int *stack = &s_lds[WITH_NODES ? threadIdx.x : 0];
     const int lane = (int)(threadIdx.x & 63);
     const uint32_t nl = (uint32_t)P.S.n_lights;
-    const ShardMap sm_s = shard_map(&Qs.counts[CNT_HITS(Qs.generation)], Qs.hit_shard_cap, nl);
+    const ShardMap sm_s = shard_map_by_light(&Qs.counts[CNT_HITS(Qs.generation)], Qs.hit_shard_cap, nl);
     const ShardMap sm_c = shard_map(&Qc.counts[CNT_RAYS(Qc.generation)], Qc.in_shard_cap, 1u);
     const long long n_s = (long long)sm_s.total, total = n_s + (long long)sm_c.total;
     if ((long long)blockIdx.x * (blockDim.x >> 6) >= total) return;
@@ -668,7 +667,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
         if (retry) continue;
         bool shaded = false;
         for (int gg = 0; gg < gd && !shaded; ++gg) {
-            const ShardMap sm_s = local_map(nl ? cnt[CNT_HITS(gg)] : 0u, L.hit_cap, nl);
+            ShardMap sm_s = local_map(nl ? cnt[CNT_HITS(gg)] : 0u, L.hit_cap, 1u);     // by light: a chunk per light for every 64 hits
+            sm_s.total *= nl;
             const uint32_t t = take(12 + gg, sm_s.total);
             if (t != ~0u) {
                 const QueueSet Qs = queue_set(gg);

@@ -1103,6 +1103,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     P.div_blocks_x = make_fastdiv((uint32_t)P.blocks_x);
     P.div_n = make_fastdiv((uint32_t)N);
     P.div_band = make_fastdiv((uint32_t)band);
+    P.div_lights = make_fastdiv((uint32_t)(P.S.n_lights > 0 ? P.S.n_lights : 1));
     P.cull_closest = may_cull ? 1 : 0;
     P.cull_shadow = (may_cull && !ctx->any_transparent_sphere) ? 1 : 0;
 
