@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #define DEV __device__ __forceinline__
+#define DEV_HOST_INLINE __host__ __device__ __forceinline__
 
 struct d3 { double x, y, z; };
 DEV d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }

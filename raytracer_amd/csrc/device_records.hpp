@@ -118,6 +118,7 @@ struct FrameParams {
     rt_camera cam;
     int32_t N;                   // samples per axis
     double aperture;
+    double spw;                  // sub-pixel width cam.pix_width / N (Camera.h:158), the same for every sample: divided once, on the host
     uint32_t flags, seed;
     int32_t band_rows, n_parts, part, local_rows;
     int32_t blocks_x;            // 8x8-pixel blocks per row of blocks (primary sample ordering)

@@ -69,7 +69,7 @@ DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, i
     const uint32_t sample = (uint32_t)(si * N + sj);
     double p, q, r;
     if (N > 1) {
-        double spw = c.pix_width / N;
+        const double spw = P.spw;
         double randX = normed_rand(gpix, sample, 0, P.seed);
         double randY = normed_rand(gpix, sample, 1, P.seed);
         randX -= .5;

@@ -194,6 +194,18 @@ static int upload(rt_ctx *ctx, const T *src, size_t n, const T **dst)
     return RT_OK;
 }
 
+// The jitter of a sample is (rand() % 1000) / 1000.0 (Camera.h:99-103); the kernels form that quotient without dividing
+// (thousandth() in shading.hpp), which is exact for each of the thousand numerators: checked here, once per context.
+static bool rand_quotients_exact()
+{
+    for (int k = 0; k < 1000; ++k) {
+        volatile double num = (double)k, den = 1000.0;
+        const double by_division = num / den;
+        if (thousandth((double)k) != by_division) return false;
+    }
+    return true;
+}
+
 extern "C" int rt_device_count(int *count)
 {
     if (!count) return fail(RT_ERR_INVALID, "rt_device_count: null argument");
@@ -225,6 +237,7 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev_s[k], hipEventDisableTiming));
     }
     for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_batch[k], hipEventDisableTiming));
+    if (!rand_quotients_exact()) return fail(RT_ERR_DEVICE, "rt_create: k / 1000 by fused multiply-adds differs from the division");
     HIP_TRY(hipEventCreate(&ctx->ev_begin));
     HIP_TRY(hipEventCreate(&ctx->ev_end));
     // the frame's totals, then the two counter blocks, in one allocation: a frame's first memset clears the totals and
@@ -1103,6 +1116,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     P.div_blocks_x = make_fastdiv((uint32_t)P.blocks_x);
     P.div_n = make_fastdiv((uint32_t)N);
     P.div_band = make_fastdiv((uint32_t)band);
+    P.spw = cam->pix_width / N;
     P.div_lights = make_fastdiv((uint32_t)(P.S.n_lights > 0 ? P.S.n_lights : 1));
     P.cull_closest = may_cull ? 1 : 0;
     P.cull_shadow = (may_cull && !ctx->any_transparent_sphere) ? 1 : 0;

@@ -112,8 +112,17 @@ DEV uint32_t hash_rng(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t se
     h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
     return h;
 }
+// k / 1000.0 for the integers k = 0..999 without the division: q = RN(k * c) with c = RN(1/1000), the residual k - 1000 q
+// is exact in a fused multiply-add, and RN(q + residual * c) is the correctly rounded quotient -- for every one of the
+// thousand values, which rt_create checks one by one against the host's division (rand_quotients_exact in rt_device.hip).
+DEV_HOST_INLINE double thousandth(double k)
+{
+    const double q = k * 0.001;
+    const double r = __builtin_fma(-1000.0, q, k);
+    return __builtin_fma(r, 0.001, q);
+}
 DEV double normed_rand(uint32_t pixel, uint32_t sample, uint32_t dim, uint32_t seed)
 {
-    return (double)(hash_rng(pixel, sample, dim, seed) % 1000u) / 1000.0;
+    return thousandth((double)(hash_rng(pixel, sample, dim, seed) % 1000u));
 }
 
