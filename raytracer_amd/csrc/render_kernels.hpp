@@ -133,6 +133,7 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
         coef = r3.y;
         pixel = (uint32_t)__double2loint(r4.x);
         meta = (uint32_t)__double2hiint(r4.x);
+        if (pixel == RAY_NONE) active = false;          // a record that only fills its chunk up
     }
 
     double best_t = 0;
@@ -195,9 +196,14 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     const unsigned long long mask_h = __ballot(want_hit), mask_a = __ballot(want_refr), mask_b = __ballot(want_refl);
     const uint32_t n_h = (uint32_t)__popcll(mask_h), n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b);
     uint32_t base_h = 0, base_r = 0;
+    // places taken: what is pushed, or (whole_chunks) that rounded up to whole chunks, the fillers counted apart for the statistics
+    const bool whole = PRIMARY && Q.whole_chunks != 0;
+    const uint32_t take_h = whole ? (n_h + 63u) & ~63u : n_h, take_r = whole ? (n_a + n_b + 63u) & ~63u : n_a + n_b;
     if (lane == 0) {
-        if (n_h) base_h = atomicAdd(&Q.counts[CNT_HITS(Q.generation) + shard], n_h);
-        if (n_a + n_b) base_r = atomicAdd(&Q.counts[CNT_RAYS(Q.generation + 1) + shard], n_a + n_b);
+        if (n_h) base_h = atomicAdd(&Q.counts[CNT_HITS(Q.generation) + shard], take_h);
+        if (n_a + n_b) base_r = atomicAdd(&Q.counts[CNT_RAYS(Q.generation + 1) + shard], take_r);
+        if (take_h != n_h) atomicAdd(&Q.counts[CNT_PAD_HITS + shard], take_h - n_h);
+        if (take_r != n_a + n_b) atomicAdd(&Q.counts[CNT_PAD_RAYS + shard], take_r - (n_a + n_b));
     }
     base_h = (uint32_t)__shfl((int)base_h, 0);
     base_r = (uint32_t)__shfl((int)base_r, 0);
@@ -210,6 +216,16 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
         (want_refl && slot_b >= Q.out_shard_cap))
         Q.counts[CNT_OVERFLOW] = 1u;
 
+    if (whole) {
+        // the fillers: of a record only the word that marks it is written (at most 63 of either kind, one per lane)
+        const uint32_t fill_h = base_h + n_h + (uint32_t)lane, fill_r = base_r + n_a + n_b + (uint32_t)lane;
+        if (n_h + (uint32_t)lane < take_h && fill_h < Q.hit_shard_cap) {
+            HitRec *dst = (HitRec *)((char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + fill_h) * Q.hit_stride);
+            ((__attribute__((address_space(1))) rec_v2d *)dst)[3] = rec_pack(0.0, __hiloint2double(-1, (int)HIT_NONE));
+        }
+        if (n_a + n_b + (uint32_t)lane < take_r && fill_r < Q.out_shard_cap)
+            ((__attribute__((address_space(1))) rec_v2d *)&Q.rays_out[(size_t)shard * Q.out_shard_cap + fill_r])[4] = rec_pack_words(RAY_NONE, 0u, 0u, 0u);
+    }
     if (want_hit && slot_h < Q.hit_shard_cap) {
         const d3 vv = unit3(sub3(o, Pt));
         HitRec *dst = (HitRec *)((char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + slot_h) * Q.hit_stride);
@@ -237,12 +253,12 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
                               rec_pack_words(pixel, (uint32_t)(L - 1), 0u, 0u)};
         rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_b], q);
     }
-    if (Q.commit && n_a + n_b) {
+    if (Q.commit && take_r) {
         // (k_local) the rays are written: count them into the 64-record pieces of the list they lie in, so that a piece
         // that is full can be traced before the rest of this generation is done
         __threadfence_block();
         if (lane == 0) {
-            uint32_t s0 = base_r, e0 = base_r + n_a + n_b;
+            uint32_t s0 = base_r, e0 = base_r + take_r;
             if (e0 > Q.out_shard_cap) e0 = Q.out_shard_cap;
             while (s0 < e0) {
                 const uint32_t ce = (s0 | 63u) + 1u < e0 ? (s0 | 63u) + 1u : e0;
@@ -355,11 +371,11 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
 #define STAMP_SEL (8 + Q.generation)
     int shard, li;
     const int item = shard_locate_by_light(smap, (uint32_t)chunk, P.div_lights, &shard, &li);      // one light per chunk
-    const bool active = item >= 0;
-    const uint32_t h = active ? (uint32_t)item : 0u;
+    const uint32_t h = item >= 0 ? (uint32_t)item : 0u;
     const HitRec *hr = (const HitRec *)((const char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + h) * Q.hit_stride);
     // head of the record: P, weight, pixel, prim, material -- four 16-byte pieces fetched together
     const rec_v2d h0 = rec_load(hr, 0), h1 = rec_load(hr, 1), h3 = rec_load(hr, 3);
+    const bool active = item >= 0 && ((uint32_t)__double2loint(h3.y) & ~HIT_FLAT) != HIT_NONE;      // (not a record that only fills its chunk up)
     const d3 Pt = mk3(h0.x, h0.y, h1.x);
     const double weight = h3.x;
     const int hit_prim = __double2hiint(h3.y);
@@ -1116,6 +1132,8 @@ DEV void collect_counts(const uint32_t *counts, unsigned long long *totals, int 
     for (int g = 0; g < 6; ++g) {
         unsigned long long r = (g == 0) ? 0ull : counts[CNT_RAYS(g) + lane];
         unsigned long long h = counts[CNT_HITS(g) + lane];
+        if (g == 0) h -= counts[CNT_PAD_HITS + lane];        // records that only fill chunks up are no hits and no rays
+        if (g == 1) r -= counts[CNT_PAD_RAYS + lane];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             r += __shfl_down(r, off);

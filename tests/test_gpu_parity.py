@@ -377,6 +377,38 @@ def test_self_contained_blocks_share_out_any_frame(gpu, scene, res):
         gpu.set_option("fused", -1)
 
 
+@pytest.mark.parametrize("scene,res,n", [("teapot-3", (300, 200), 2), ("refract", (256, 192), 1), ("balls", (200, 136), 1), ("glass", (160, 160), 1)])
+def test_primary_pass_pushes_whole_chunks(gpu, oracle_frame, scene, res, n):
+    """The primary pass rounds what a wave pushes up to whole chunks of 64 records and marks the fillers, so that a chunk of
+    the passes that follow is one wave's output; the fillers are no rays and no hits: same frame, same ray and hit counts
+    as with packed records and as the oracle, on every path (self-contained blocks, paired passes, a launch per pass)."""
+    s = load_scene(gpu, scene)
+    cam = s.camera(*res)
+    o = oracle_frame(scene, res=res, num_samples=n)
+    gpu.set_option("fused", 0)
+    try:
+        for path in ({"local": 1}, {"local": 0, "pair": 1}, {"local": 0, "pair": 0}):
+            for k, v in path.items():
+                gpu.set_option(k, v)
+            frames = []
+            for whole in (1, 0):
+                gpu.set_option("whole_chunks", whole)
+                frames.append(gpu.render(cam, num_samples=n, flags=rt.FLAG_KEEP_ZERO_WEIGHT))
+            for g in frames:
+                assert_frames_match(g, o, tol=1e-6)
+                assert g["stats"]["closest_rays"] == o["counters"]["closest_rays"], path
+                assert g["stats"]["shadow_rays"] == o["counters"]["shadow_rays"], path
+                assert g["stats"]["queue_overflow"] == 0
+            assert frames[0]["stats"]["rays_per_generation"] == frames[1]["stats"]["rays_per_generation"], path
+            assert frames[0]["stats"]["hits_per_generation"] == frames[1]["stats"]["hits_per_generation"], path
+            assert np.array_equal(frames[0]["rgb_u8"], frames[1]["rgb_u8"]), path
+    finally:
+        gpu.set_option("whole_chunks", 1)
+        gpu.set_option("local", -1)
+        gpu.set_option("pair", -1)
+        gpu.set_option("fused", -1)
+
+
 def test_primary_pass_in_units_drawn_while_it_runs(gpu, oracle_frame):
     """A primary pass with many chunks per wave hands its chunks out in units while it runs (a counter in memory, a
     permuted order, records sharded by unit) instead of giving every block a fixed share: the same frame and ray counts
