@@ -213,8 +213,8 @@ int rt_noalloc_scratch_bytes(size_t *bytes);
  * "verbose", "queue_growth" (1..32); "pair", "overlap", "fused", "local" (1 forces, 0 forbids, -1 leaves to the frame's
  * size: paired passes, passes on two streams, the lane-per-sample kernel, the self-contained blocks), "local_threads"
  * (256, 512, 1024), "local_rotate" (places a block's share of the primary chunks moves on per round, -1 = by image
- * width), "local_min_chunks" (primary chunks a self-contained block gets at least, 0 = four), "whole_chunks" (0: the primary
- * pass packs its records like every other pass instead of pushing whole chunks), "units" (0: the primary pass keeps fixed shares per block), "lightcam_host" (1: light-camera trees
+ * width), "local_min_chunks" (primary chunks a self-contained block gets at least, 0 = four), "whole_chunks" (how many
+ * generations of closest-hit passes push whole chunks of records, 0..6, -1 = default), "units" (0: the primary pass keeps fixed shares per block), "lightcam_host" (1: light-camera trees
  * built on the host), "lightcam_pool" (128..1536: places used of the pool of pending cells that a wave's 64 density
  * queries share; a full pool slows the pass down, it loses nothing); and for the next rt_upload_scene "leaf_max"
  * (1..4), "split_budget" (percent). */

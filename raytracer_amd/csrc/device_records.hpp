@@ -139,12 +139,12 @@ struct FrameParams {
 #define CNT_RAYS(g) ((g) * N_SHARDS)             // g = 0..6
 #define CNT_HITS(g) ((7 + (g)) * N_SHARDS)       // g = 0..5
 #define CNT_DEFER(g) ((13 + (g)) * N_SHARDS)     // g = 0..5: deferred light-camera evaluations
-#define CNT_PAD_HITS (19 * N_SHARDS)              // of the hit records of generation 0, how many are fillers (QueueSet::whole_chunks)
-#define CNT_PAD_RAYS (20 * N_SHARDS)              // ... and of the ray records of generation 1
-#define CNT_OVERFLOW (21 * N_SHARDS)
-#define CNT_UNITS (21 * N_SHARDS + 4)            // units of work handed out by a primary pass that shares its chunks out on the device
-#define CNT_LCWORK (21 * N_SHARDS + 5)           // 64-query chunks handed out by the light-camera density pass
-#define CNT_WORDS (21 * N_SHARDS + 16)
+#define CNT_PAD_HITS(g) ((19 + (g)) * N_SHARDS)  // g = 0..5: of the hit records of generation g, how many are fillers (QueueSet::whole_chunks)
+#define CNT_PAD_RAYS(g) ((25 + (g)) * N_SHARDS)  // g = 1..6: ... and of the ray records of generation g
+#define CNT_OVERFLOW (32 * N_SHARDS)
+#define CNT_UNITS (32 * N_SHARDS + 4)            // units of work handed out by a primary pass that shares its chunks out on the device
+#define CNT_LCWORK (32 * N_SHARDS + 5)           // 64-query chunks handed out by the light-camera density pass
+#define CNT_WORDS (32 * N_SHARDS + 16)
 
 struct QueueSet {
     RayRec *rays_in;
@@ -162,7 +162,7 @@ struct QueueSet {
                                      // block of 8x8 pixels (chunk_begin is a multiple of N*N)
     int64_t block_row0;              // PRIMARY only: row and column, in 8x8-pixel blocks, of the batch's first block
     int32_t block_col0;
-    uint32_t whole_chunks;           // PRIMARY only: every wave that pushes hit or ray records takes whole chunks of 64 places and fills
+    uint32_t whole_chunks;           // closest-hit passes: every wave that pushes hit or ray records takes whole chunks of 64 places and fills
                                      //   the rest with records marked empty (pixel HIT_NONE / RAY_NONE): a chunk of the passes that read
                                      //   them is then the output of ONE wave, neighbouring samples, not the tail of one wave's push and the
                                      //   head of another's from elsewhere in the image

@@ -197,13 +197,13 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     const uint32_t n_h = (uint32_t)__popcll(mask_h), n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b);
     uint32_t base_h = 0, base_r = 0;
     // places taken: what is pushed, or (whole_chunks) that rounded up to whole chunks, the fillers counted apart for the statistics
-    const bool whole = PRIMARY && Q.whole_chunks != 0;
+    const bool whole = Q.whole_chunks != 0;
     const uint32_t take_h = whole ? (n_h + 63u) & ~63u : n_h, take_r = whole ? (n_a + n_b + 63u) & ~63u : n_a + n_b;
     if (lane == 0) {
         if (n_h) base_h = atomicAdd(&Q.counts[CNT_HITS(Q.generation) + shard], take_h);
         if (n_a + n_b) base_r = atomicAdd(&Q.counts[CNT_RAYS(Q.generation + 1) + shard], take_r);
-        if (take_h != n_h) atomicAdd(&Q.counts[CNT_PAD_HITS + shard], take_h - n_h);
-        if (take_r != n_a + n_b) atomicAdd(&Q.counts[CNT_PAD_RAYS + shard], take_r - (n_a + n_b));
+        if (take_h != n_h) atomicAdd(&Q.counts[CNT_PAD_HITS(Q.generation) + shard], take_h - n_h);
+        if (take_r != n_a + n_b) atomicAdd(&Q.counts[CNT_PAD_RAYS(Q.generation + 1) + shard], take_r - (n_a + n_b));
     }
     base_h = (uint32_t)__shfl((int)base_h, 0);
     base_r = (uint32_t)__shfl((int)base_r, 0);
@@ -609,6 +609,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_local(FramePa
         Q.hit_shard_cap = L.hit_cap;
         Q.generation = g;
         Q.unit_chunks = 0;
+        Q.whole_chunks = (uint32_t)g < Q0.whole_chunks ? 1u : 0u;        // (Q0.whole_chunks: so many generations push whole chunks)
         Q.deferred = L.deferred;
         Q.defer_shard_cap = L.defer_shard_cap;
         Q.defer_counts = L.deferred ? &L.frame_counts[CNT_DEFER(0)] : nullptr;
@@ -1132,8 +1133,8 @@ DEV void collect_counts(const uint32_t *counts, unsigned long long *totals, int 
     for (int g = 0; g < 6; ++g) {
         unsigned long long r = (g == 0) ? 0ull : counts[CNT_RAYS(g) + lane];
         unsigned long long h = counts[CNT_HITS(g) + lane];
-        if (g == 0) h -= counts[CNT_PAD_HITS + lane];        // records that only fill chunks up are no hits and no rays
-        if (g == 1) r -= counts[CNT_PAD_RAYS + lane];
+        h -= counts[CNT_PAD_HITS(g) + lane];                 // records that only fill chunks up are no hits and no rays
+        if (g > 0) r -= counts[CNT_PAD_RAYS(g) + lane];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             r += __shfl_down(r, off);

@@ -86,7 +86,7 @@ struct DebugOptions {
     int fused = -1;                 // 1: always the one-launch kernel, 0: never, -1: by frame size
     int local_threads = 1024;       // block size of the block-local kernel (256, 512 or 1024)
     int local_min_chunks = 0;       // primary chunks a block of the block-local kernel gets at least (0: four)
-    int whole_chunks = 1;           // the primary pass pushes whole chunks of records (0: packed, as every other pass)
+    int whole_chunks = 2;           // the closest-hit passes of so many generations push whole chunks of records (0: packed)
     int local_rotate = -1;          // places a block's share of the primary chunks moves on per round (-1: chosen from the image width)
     int local = -1;                 // 1: always the block-local one-launch kernel where it applies, 0: never, -1: by frame size
     int units = 1;                  // 0: the primary pass never shares its chunks out on the device (every block keeps to a fixed share)
@@ -1447,9 +1447,11 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         // the batch two before it (same counter block).  Pixel accumulation is atomic, so the
         // order in which the passes finish does not matter.
         hipStream_t sb = overlap ? ctx->stream2 : st;
-        // the primary pass pushes whole chunks (QueueSet::whole_chunks); not in the entry point that allocates nothing, whose
-        // queues are cut to what the scratch array holds
-        const bool whole_chunks = !noalloc && ctx->dbg.whole_chunks != 0;
+        // The closest-hit passes of the first generations push whole chunks (QueueSet::whole_chunks).  Where a hit can spawn
+        // two rays the queues of the later generations are sized by expected growth, not by the worst case, and fillers
+        // could overflow them: only the primary pass then.  Not in the entry point that allocates nothing, whose queues
+        // are cut to what the scratch array holds.
+        const int whole_generations = noalloc ? 0 : (ctx->any_transparent && ctx->dbg.whole_chunks > 1 ? 1 : ctx->dbg.whole_chunks);
         const bool timing = (o->flags & RT_FLAG_TIMING) != 0;
         long long batch_no = 0;
         if (use_fused) {
@@ -1509,7 +1511,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             QueueSet Q{};
             Q.counts = counts;
             Q.hit_stride = all_flat ? 64u : 128u;
-            Q.whole_chunks = whole_chunks ? 1u : 0u;
+            Q.whole_chunks = (uint32_t)whole_generations;      // (k_local: the number of generations)
             Q.chunk_begin = 0;
             Q.chunk_end = n_chunks;
             Q.block_row0 = 0;
@@ -1556,7 +1558,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.hit_stride = all_flat ? 64u : 128u;
                 Q.generation = g;
                 Q.unit_chunks = g == 0 ? QP.unit_chunks : 0u;
-                Q.whole_chunks = (g == 0 && whole_chunks) ? 1u : 0u;
+                Q.whole_chunks = g < whole_generations ? 1u : 0u;
                 Q.unit_mult = 0;
                 if (g == 0 && QP.unit_chunks) {
                     // Units are handed out in the order (k * m) mod n, m near 0.618 n and sharing no factor with n:
@@ -1626,7 +1628,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.hit_stride = all_flat ? 64u : 128u;
                 Q.generation = g;
                 Q.unit_chunks = g == 0 ? QP.unit_chunks : 0u;
-                Q.whole_chunks = (g == 0 && whole_chunks) ? 1u : 0u;
+                Q.whole_chunks = g < whole_generations ? 1u : 0u;
                 Q.unit_mult = 0;
                 if (g == 0 && QP.unit_chunks) {
                     // Units are handed out in the order (k * m) mod n, m near 0.618 n and sharing no factor with n:
@@ -1846,7 +1848,7 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "local") ctx->dbg.local = (int)value;
     else if (n == "local_threads") ctx->dbg.local_threads = (value == 256 || value == 512) ? (int)value : 1024;
     else if (n == "local_min_chunks") ctx->dbg.local_min_chunks = value < 0 ? 0 : (int)(value & 0xffff);
-    else if (n == "whole_chunks") ctx->dbg.whole_chunks = value != 0 ? 1 : 0;
+    else if (n == "whole_chunks") ctx->dbg.whole_chunks = value < 0 ? 2 : (value > 6 ? 6 : (int)value);
     else if (n == "local_rotate") ctx->dbg.local_rotate = value < 0 ? -1 : (int)(value & 0xffff);
     else if (n == "overlap") ctx->dbg.overlap = (int)value;
     else if (n == "pair") ctx->dbg.pair = (int)value;

@@ -379,8 +379,8 @@ def test_self_contained_blocks_share_out_any_frame(gpu, scene, res):
 
 @pytest.mark.parametrize("scene,res,n", [("teapot-3", (300, 200), 2), ("refract", (256, 192), 1), ("balls", (200, 136), 1), ("glass", (160, 160), 1)])
 def test_primary_pass_pushes_whole_chunks(gpu, oracle_frame, scene, res, n):
-    """The primary pass rounds what a wave pushes up to whole chunks of 64 records and marks the fillers, so that a chunk of
-    the passes that follow is one wave's output; the fillers are no rays and no hits: same frame, same ray and hit counts
+    """The closest-hit passes of the first generations round what a wave pushes up to whole chunks of 64 records and mark the
+    fillers, so that a chunk of the passes that follow is one wave's output; the fillers are no rays and no hits: same frame, same ray and hit counts
     as with packed records and as the oracle, on every path (self-contained blocks, paired passes, a launch per pass)."""
     s = load_scene(gpu, scene)
     cam = s.camera(*res)
@@ -391,7 +391,7 @@ def test_primary_pass_pushes_whole_chunks(gpu, oracle_frame, scene, res, n):
             for k, v in path.items():
                 gpu.set_option(k, v)
             frames = []
-            for whole in (1, 0):
+            for whole in (-1, 6, 1, 0):
                 gpu.set_option("whole_chunks", whole)
                 frames.append(gpu.render(cam, num_samples=n, flags=rt.FLAG_KEEP_ZERO_WEIGHT))
             for g in frames:
@@ -399,11 +399,12 @@ def test_primary_pass_pushes_whole_chunks(gpu, oracle_frame, scene, res, n):
                 assert g["stats"]["closest_rays"] == o["counters"]["closest_rays"], path
                 assert g["stats"]["shadow_rays"] == o["counters"]["shadow_rays"], path
                 assert g["stats"]["queue_overflow"] == 0
-            assert frames[0]["stats"]["rays_per_generation"] == frames[1]["stats"]["rays_per_generation"], path
-            assert frames[0]["stats"]["hits_per_generation"] == frames[1]["stats"]["hits_per_generation"], path
-            assert np.array_equal(frames[0]["rgb_u8"], frames[1]["rgb_u8"]), path
+            for f in frames[:-1]:
+                assert f["stats"]["rays_per_generation"] == frames[-1]["stats"]["rays_per_generation"], path
+                assert f["stats"]["hits_per_generation"] == frames[-1]["stats"]["hits_per_generation"], path
+                assert np.array_equal(f["rgb_u8"], frames[-1]["rgb_u8"]), path
     finally:
-        gpu.set_option("whole_chunks", 1)
+        gpu.set_option("whole_chunks", -1)
         gpu.set_option("local", -1)
         gpu.set_option("pair", -1)
         gpu.set_option("fused", -1)
