@@ -312,7 +312,7 @@ def main():
         # ---- roofline of the dominant kernel: the one with the largest total time among the launches of a frame
         build_id = rt.build_id()
         if kt["shadow_launches"] == 0 and kt["closest_launches"] == kt["primary_launches"]:
-            classes = {"k_fused": ("fused", kt["primary_ms"], kt["primary_launches"], kt["closest_rays"] + kt["shadow_rays"])}
+            classes = {"k_local / k_fused (the frame is one launch)": ("fused", kt["primary_ms"], kt["primary_launches"], kt["closest_rays"] + kt["shadow_rays"])}
         else:
             classes = {
                 "k_closest<true, true>": ("primary", kt["primary_ms"], kt["primary_launches"], kt["primary_rays"]),
