@@ -295,6 +295,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
         uint32_t id = blockIdx.x;
         if (Q.unit_mult && id < nu) id = (uint32_t)(((unsigned long long)id * Q.unit_mult) % nu);
         ring[0] = (int)((1u << 24) | id);
+        // The other three places start with a tag no unit waits for.  LDS keeps what the last block on this compute unit
+        // left there -- the ring of the previous frame's pass, whose k-th word carries the very tag this block's k-th unit
+        // waits for -- and a wave that gets to a unit before its word is written (waves race ahead where chunks are
+        // background) would take that block's unit for its own: some chunks traced twice, others never.
+        ring[1] = ring[2] = ring[3] = 0;
     }
     STAMP(1);
     fill_node_cache(P.S, BVH);      // ends with the block's barrier
