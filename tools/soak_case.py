@@ -9,7 +9,7 @@ g = rt.Renderer(0)
 s = rt.Scene.load(name); g.upload(s); cam = s.camera(rx, ry)
 u8 = torch.zeros((cam.resy, cam.resx, 3), dtype=torch.uint8, device="cuda:0")
 hit = torch.zeros((cam.resy, cam.resx), dtype=torch.int32, device="cuda:0")
-for opts in ({}, {"pair": 0}, {"whole_chunks": 0}, {}):
+for opts in ({}, {"pair": 0}):
     for k, v in opts.items(): g.set_option(k, v)
     first = None; n = 0; bad = 0; t0 = time.time()
     while time.time() - t0 < budget:
