@@ -235,6 +235,30 @@ def test_malformed_scene_arrays_are_rejected_before_reaching_the_gpu(gpu):
     gpu.upload(s)     # the context is still usable
 
 
+def test_repeated_frames_are_identical(gpu):
+    """The same mid-size frame many times over (primary pass handed out in units, paired passes, whole chunks): ray and hit
+    counts, the hit map and the image repeat exactly.  A hand-over between waves that can go wrong shows here as a frame
+    with a few chunks traced twice or never (tools/soak.py runs the long version of this over eight cases)."""
+    import torch
+    s = rt.Scene.load("teapot")
+    gpu.upload(s)
+    cam = s.camera(2048, 2048)
+    u8 = torch.zeros((cam.resy, cam.resx, 3), dtype=torch.uint8, device="cuda:0")
+    hit = torch.zeros((cam.resy, cam.resx), dtype=torch.int32, device="cuda:0")
+    first = None
+    for k in range(120):
+        hit.fill_(-7)
+        torch.cuda.synchronize()
+        st = gpu.render_device(cam, rgb_u8_ptr=u8.data_ptr(), hit_id_ptr=hit.data_ptr(), num_samples=2, flags=rt.FLAG_PHONG_NORMALS)
+        key = (tuple(st["rays_per_generation"]), tuple(st["hits_per_generation"]), st["shadow_rays"], st["queue_overflow"],
+               int((hit == -7).sum()), int(hit.to(torch.int64).sum()), int(u8.to(torch.int64).sum()))
+        if first is None:
+            first = key
+        assert key == first, k
+    assert first[3] == 0 and first[4] == 0
+    s.close()
+
+
 def test_8k_frame_properties(gpu, oracle_mod):
     """teapot-3 at 7680x4320, 16 spp (the benchmark frame)."""
     s = rt.Scene.load("teapot-3")
