@@ -398,8 +398,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "scene": scene_name + ".nff", "resolution": [resx, resy],
                        "spp": N * N, "rays_per_frame": rays / steps,
-                       "partition": "%d-row bands round-robin over %d GPU(s), %s gather of RGB8"
-                                    % (band or resy, world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal)")},
+                       "partition": ("the whole frame on one GPU (no gather)" if world == 1 else
+                                     "%d-row bands round-robin over %d GPUs, %s gather of RGB8"
+                                     % (band, world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal)"))},
         }
         line["frame_sha256"] = frame_sha
         line["frame_matches_pinned"] = (frame_sha == pinned) if pinned else None

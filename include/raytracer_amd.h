@@ -192,8 +192,10 @@ int rt_set_memory_budget(rt_ctx *ctx, size_t bytes);
  * If a frame outgrows them, rt_sync returns RT_ERR_CAPACITY (the outputs are incomplete) and the context doubles
  * the multiple for its next frame; rt_render does that re-rendering by itself and only returns a complete frame. */
 
-/* rt_render for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and results as
+/* rt_render for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc,
+ * processes whose memory is all handed out).  It has no counterpart in the reference.  It is a blocking call on the
+ * context's own streams (it synchronises and reads a few words back), so it cannot be recorded into a HIP graph
+ * by stream capture; what it guarantees is that no device or host-pinned memory is allocated or freed.  Same arguments and results as
  * rt_render with device output buffers (out->on_device must be 1), but it calls no hipMalloc/hipFree and creates
  * no events: accumulation frame, counters and queues live in a static device array of rt_noalloc_scratch_bytes()
  * (128 MiB) that every GPU holds once per process.  Limits, each an error and never a fallback:

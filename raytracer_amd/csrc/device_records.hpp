@@ -144,6 +144,7 @@ struct FrameParams {
 #define CNT_OVERFLOW (32 * N_SHARDS)
 #define CNT_UNITS (32 * N_SHARDS + 4)            // units of work handed out by a primary pass that shares its chunks out on the device
 #define CNT_LCWORK (32 * N_SHARDS + 5)           // 64-query chunks handed out by the light-camera density pass
+#define CNT_ARRIVED (32 * N_SHARDS + 6)          // blocks of the diagnostic launch that fills the LDS ring words (k_poison_ring)
 #define CNT_WORDS (32 * N_SHARDS + 16)
 
 struct QueueSet {
@@ -158,6 +159,7 @@ struct QueueSet {
     int32_t generation;
     uint32_t unit_chunks;        // PRIMARY only: chunks per unit of work drawn from CNT_UNITS (a power of two), or 0: every block keeps to its own chunks
     uint32_t unit_mult;          // ... the k-th unit handed out is number (k * unit_mult) mod (number of units); 0: number k
+                                 //     (bit 31, diagnostic: unit numbers are handed over late, see k_poison_ring)
     int64_t chunk_begin, chunk_end;  // PRIMARY only: 64-sample chunks of the primary ordering; a batch begins at a
                                      // block of 8x8 pixels (chunk_begin is a multiple of N*N)
     int64_t block_row0;              // PRIMARY only: row and column, in 8x8-pixel blocks, of the batch's first block

@@ -293,13 +293,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
     if (PRIMARY && threadIdx.x == 0) {
         const uint32_t nu = Q.unit_chunks ? (uint32_t)((Q.chunk_end - Q.chunk_begin + Q.unit_chunks - 1) / Q.unit_chunks) : 0u;
         uint32_t id = blockIdx.x;
-        if (Q.unit_mult && id < nu) id = (uint32_t)(((unsigned long long)id * Q.unit_mult) % nu);
+        if ((Q.unit_mult & 0x7fffffffu) && id < nu) id = (uint32_t)(((unsigned long long)id * (Q.unit_mult & 0x7fffffffu)) % nu);
         ring[0] = (int)((1u << 24) | id);
         // The other three places start with a tag no unit waits for.  LDS keeps what the last block on this compute unit
         // left there -- the ring of the previous frame's pass, whose k-th word carries the very tag this block's k-th unit
         // waits for -- and a wave that gets to a unit before its word is written (waves race ahead where chunks are
         // background) would take that block's unit for its own: some chunks traced twice, others never.
+#ifndef RT_TEST_STALE_RING      // (a test build leaves them as they are, to show that the ring_poison test sees the fault)
         ring[1] = ring[2] = ring[3] = 0;
+#endif
     }
     STAMP(1);
     fill_node_cache(P.S, BVH);      // ends with the block's barrier
@@ -330,10 +332,29 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
                 if (r == (G >> 1)) {
                     uint32_t id = gridDim.x + atomicAdd(&Q.counts[CNT_UNITS], 1u);
                     if (id >= n_units) id = 0xffffffu;
-                    else if (Q.unit_mult) id = (uint32_t)(((unsigned long long)id * Q.unit_mult) % n_units);
+                    else if (Q.unit_mult & 0x7fffffffu) id = (uint32_t)(((unsigned long long)id * (Q.unit_mult & 0x7fffffffu)) % n_units);
+                    // (diagnostic, bit 31 of unit_mult: the word is handed over late, so that the block's other waves get
+                    // to the next unit first and have to wait for it -- with k_poison_ring's words in LDS meanwhile)
+                    if (Q.unit_mult >> 31)
+                        for (int k = 0; k < 12; ++k) __builtin_amdgcn_s_sleep(127);
                     ring[(j + 1) & 3] = (int)((((j + 2) & 0xffu) << 24) | id);
                 }
-                while (((uint32_t)(word = ring[j & 3]) >> 24) != ((j + 1) & 0xffu)) __builtin_amdgcn_s_sleep(1);
+                // The word of unit j carries tag j + 1.  The wait is bounded: a tag ahead of the awaited one (the place was
+                // written again before this wave read it) or a word that never arrives ends the block's share with the
+                // frame marked incomplete (the host reports it and renders the frame again) instead of a spin without end.
+                const uint32_t want = (j + 1) & 0xffu;
+                uint32_t spins = 0;
+                for (;;) {
+                    word = ring[j & 3];
+                    const uint32_t ahead = (((uint32_t)word >> 24) - want) & 0xffu;
+                    if (ahead == 0) break;
+                    if ((ahead < 128u && (ahead & 3u) == 0u) || ++spins > (1u << 22)) {
+                        Q.counts[CNT_OVERFLOW] = 1u;
+                        word = (int)0xffffffu;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
             const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane(word) & 0xffffffu;
             if (id >= n_units) break;                  // the counter has run past the batch: nothing left for this block
@@ -353,6 +374,25 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
 #undef STAMP_SEL
 }
 
+
+// Diagnostic (option "ring_poison", run before a primary pass that hands its chunks out in units): leaves in every compute
+// unit's LDS, in the four words where that pass keeps its ring of unit numbers, the tags its blocks' units 0..3 wait for --
+// with the number of a unit that is not theirs.  LDS keeps what the last block on a compute unit wrote, so this is what the
+// ring of an earlier pass can look like to the next one; a pass that took such a word for the awaited one would trace unit
+// 0 again and again and never its own.  One block per compute unit (same block size and LDS size as the pass); a block
+// stays until all have started, so that no compute unit takes two of them and another none (bounded wait).
+__global__ __launch_bounds__(RT_BLOCK) void k_poison_ring(int ring_word, uint32_t *arrived, uint32_t blocks)
+{
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 4; ++k) ((volatile int *)s_lds)[ring_word + k] = (int)(((uint32_t)(k + 1) << 24) | 0u);
+        atomicAdd(arrived, 1u);
+        for (uint32_t spins = 0; spins < (1u << 18); ++spins) {
+            if (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= blocks) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+}
 
 #ifndef RT_MIN_WAVES_SHADOW
 #define RT_MIN_WAVES_SHADOW 4

@@ -92,6 +92,8 @@ struct DebugOptions {
     int units = 1;                  // 0: the primary pass never shares its chunks out on the device (every block keeps to a fixed share)
     int overlap = -1;               // 1: shadow passes on the second stream beside the next closest-hit pass, 0: one stream, -1: by batch size
     int pair = -1;                  // 1: shadow pass g and closest-hit pass g+1 in one launch, 0: a launch each, -1: default (paired)
+    int ring_poison = 0;            // 1: before a primary pass that hands out units, the LDS ring words of every compute unit are filled with
+                                    //    matching tags and wrong unit numbers (k_poison_ring): a deterministic form of what stale LDS can hold
     int lightcam_pool = LC_POOL;    // places used of a wave's pool of pending cells in the light-camera density pass (128..LC_POOL)
 };
 
@@ -217,6 +219,8 @@ extern "C" int rt_device_count(int *count)
     return RT_OK;
 }
 
+static int create_resources(rt_ctx *ctx, int device_id, const hipDeviceProp_t &prop);
+
 extern "C" int rt_create(int device_id, rt_ctx **out)
 {
     if (!out) return fail(RT_ERR_INVALID, "rt_create: null argument");
@@ -229,6 +233,19 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     rt_ctx *ctx = new rt_ctx();
     ctx->device = device_id;
+    // whatever has been created when a later step fails is given back (rt_destroy takes a half-made context)
+    const int rc = create_resources(ctx, device_id, prop);
+    if (rc != RT_OK) {
+        const std::string msg = g_error;
+        rt_destroy(ctx);
+        return fail(rc, msg);
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+static int create_resources(rt_ctx *ctx, int device_id, const hipDeviceProp_t &prop)
+{
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) ctx->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -256,7 +273,8 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
                                  (const void *)k_pair<true, SHADOW_EXACT>, (const void *)k_pair<false, SHADOW_EXACT>,
                                  (const void *)k_local<SHADOW_BVH>, (const void *)k_local<SHADOW_HYBRID>,
                                  (const void *)k_fused<true, SHADOW_BVH>, (const void *)k_fused<true, SHADOW_HYBRID>,
-                                 (const void *)k_fused<true, SHADOW_EXACT>, (const void *)k_fused<false, SHADOW_EXACT>};
+                                 (const void *)k_fused<true, SHADOW_EXACT>, (const void *)k_fused<false, SHADOW_EXACT>,
+                                 (const void *)k_poison_ring};
         for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     }
     if (device_id < RT_MAX_DEVICES) {
@@ -269,7 +287,6 @@ extern "C" int rt_create(int device_id, rt_ctx **out)
         }
         ctx->scratch = g_scratch_ptr[device_id];
     }
-    *out = ctx;
     return RT_OK;
 }
 
@@ -814,7 +831,10 @@ static int build_lightcams(rt_ctx *ctx, const std::vector<int32_t> &pairs, uint3
             lightcam::Point *bigger = nullptr;
             const size_t want = ((size_t)begins[b] + n_pts) * 2;
             HIP_TRY(hipMalloc((void **)&bigger, want * sizeof(lightcam::Point)));
-            if (begins[b] > 0) HIP_TRY(hipMemcpy(bigger, ctx->lc_packed, (size_t)begins[b] * sizeof(lightcam::Point), hipMemcpyDeviceToDevice));
+            if (begins[b] > 0 && hipMemcpy(bigger, ctx->lc_packed, (size_t)begins[b] * sizeof(lightcam::Point), hipMemcpyDeviceToDevice) != hipSuccess) {
+                (void)hipFree(bigger);
+                return fail(RT_ERR_DEVICE, "light cameras: carrying the packed impacts over to a larger array failed");
+            }
             (void)hipFree(ctx->lc_packed);
             ctx->lc_packed = bigger;
             ctx->lc_packed_bytes = want * sizeof(lightcam::Point);
@@ -834,6 +854,8 @@ static int build_lightcams(rt_ctx *ctx, const std::vector<int32_t> &pairs, uint3
     void *dn = nullptr, *dp = nullptr;
     int32_t n_nodes = 0;
     int levels = 0;
+    std::vector<lightcam::Node> host_nodes;      // (the host builder's output)
+    std::vector<lightcam::Point> host_points;
     if (!ctx->dbg.lightcam_host) {
         rc = build_trees_on_device(ctx, st, ctx->lc_packed, begins, d_meta, &dn, &n_nodes, &dp, &levels);
         if (rc != RT_OK) return rc;
@@ -853,8 +875,9 @@ static int build_lightcams(rt_ctx *ctx, const std::vector<int32_t> &pairs, uint3
                 lightcam::build(pts, max_dist, trees[b]);
             });
         for (std::thread &t : pool) t.join();
-        std::vector<lightcam::Node> nodes(n_build);
-        std::vector<lightcam::Point> points;
+        std::vector<lightcam::Node> &nodes = host_nodes;
+        std::vector<lightcam::Point> &points = host_points;
+        nodes.assign(n_build, lightcam::Node{});
         points.reserve(n_pts);
         for (size_t b = 0; b < n_build; ++b) {
             const int32_t shift = (int32_t)nodes.size() - 1, pshift = begins[b];       // node k > 0 of tree b becomes node shift + k
@@ -869,11 +892,14 @@ static int build_lightcams(rt_ctx *ctx, const std::vector<int32_t> &pairs, uint3
         n_nodes = (int32_t)nodes.size();
         HIP_TRY(hipMalloc(&dn, sizeof(lightcam::Node) * nodes.size()));
         if (hipMalloc(&dp, sizeof(lightcam::Point) * (points.size() ? points.size() : 1)) != hipSuccess) { (void)hipFree(dn); return fail(RT_ERR_DEVICE, "hipMalloc failed for light-camera trees"); }
-        HIP_TRY(hipMemcpy(dn, nodes.data(), sizeof(lightcam::Node) * nodes.size(), hipMemcpyHostToDevice));
-        if (!points.empty()) HIP_TRY(hipMemcpy(dp, points.data(), sizeof(lightcam::Point) * points.size(), hipMemcpyHostToDevice));
     }
+    // the context owns the arrays from here on: a failure below leaves them to free_lightcams
     ctx->lc_allocs.push_back(dn);
     ctx->lc_allocs.push_back(dp);
+    if (ctx->dbg.lightcam_host) {
+        HIP_TRY(hipMemcpy(dn, host_nodes.data(), sizeof(lightcam::Node) * host_nodes.size(), hipMemcpyHostToDevice));
+        if (!host_points.empty()) HIP_TRY(hipMemcpy(dp, host_points.data(), sizeof(lightcam::Point) * host_points.size(), hipMemcpyHostToDevice));
+    }
     std::vector<unsigned long long> meta(n_build * 2);
     HIP_TRY(hipMemcpy(meta.data(), d_meta, n_build * 16, hipMemcpyDeviceToHost));
     for (size_t b = 0; b < n_build; ++b) {
@@ -1544,6 +1570,12 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             uint32_t *counts = B.counts + (size_t)par * CNT_WORDS;
             if (batch_no >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[par], 0));
             if (!(batch_no == 0 && counts0_clear)) HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
+            // (diagnostic, option "ring_poison": see k_poison_ring)
+            auto poison_ring = [&](const QueueSet &Q, uint32_t *cnt) {
+                if (!ctx->dbg.ring_poison || !Q.unit_chunks) return;
+                const unsigned resident = (unsigned)(ctx->cu_count * blocks_per_cu);
+                hipLaunchKernelGGL(k_poison_ring, dim3(resident), dim3(block), lds_closest, st, P.S.lds_ticket_word + 4, cnt + CNT_ARRIVED, resident);
+            };
             auto queue_set = [&](int g) {
                 QueueSet Q{};
                 Q.rays_in = B.rays[g & 1];
@@ -1570,7 +1602,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     unsigned long long a = (unsigned long long)((double)nu * 0.6180339887) | 1ull;
                     auto gcd = [](unsigned long long x, unsigned long long y) { while (y) { unsigned long long r = x % y; x = y; y = r; } return x; };
                     while (a > 1 && gcd(a, nu) != 1) a += 2;
-                    Q.unit_mult = (uint32_t)(a % (nu ? nu : 1));
+                    Q.unit_mult = (uint32_t)(a % (nu ? nu : 1)) | (ctx->dbg.ring_poison ? 0x80000000u : 0u);
                 }
                 Q.chunk_begin = t0;
                 Q.chunk_end = t1;
@@ -1587,6 +1619,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     if (ev) HIP_TRY(hipEventRecord(ev->first, st));
                     long long blocks = (t1 - t0 + waves_per_block - 1) / waves_per_block;
                     if (blocks > blocks0) blocks = blocks0;
+                    poison_ring(Q, counts);
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                     if (ev) HIP_TRY(hipEventRecord(ev->second, st));
@@ -1640,7 +1673,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     unsigned long long a = (unsigned long long)((double)nu * 0.6180339887) | 1ull;
                     auto gcd = [](unsigned long long x, unsigned long long y) { while (y) { unsigned long long r = x % y; x = y; y = r; } return x; };
                     while (a > 1 && gcd(a, nu) != 1) a += 2;
-                    Q.unit_mult = (uint32_t)(a % (nu ? nu : 1));
+                    Q.unit_mult = (uint32_t)(a % (nu ? nu : 1)) | (ctx->dbg.ring_poison ? 0x80000000u : 0u);
                 }
                 Q.chunk_begin = t0;
                 Q.chunk_end = t1;
@@ -1654,6 +1687,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 if (g == 0) {
                     long long blocks = (t1 - t0 + waves_per_block - 1) / waves_per_block;
                     if (blocks > blocks0) blocks = blocks0;
+                    poison_ring(Q, counts);
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                 } else {
@@ -1852,6 +1886,7 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "local_rotate") ctx->dbg.local_rotate = value < 0 ? -1 : (int)(value & 0xffff);
     else if (n == "overlap") ctx->dbg.overlap = (int)value;
     else if (n == "pair") ctx->dbg.pair = (int)value;
+    else if (n == "ring_poison") ctx->dbg.ring_poison = value != 0;
     else if (n == "lightcam_pool") ctx->dbg.lightcam_pool = value < 128 ? 128 : (value > LC_POOL ? LC_POOL : (int)value);
     else if (n == "queue_growth") ctx->growth = value < 1 ? 1 : (value > 32 ? 32 : (int)value);
     else return fail(RT_ERR_INVALID, "rt_debug_set_option: unknown option '" + n + "'");

@@ -65,6 +65,14 @@ def main():
     gz_write(os.path.join(HERE, "hide.ppm.gz"), ppm)
     golden = {"hide_ppm_sha256": hashlib.sha256(ppm).hexdigest(), "hide_ppm_scene": "glass",
               "reference_runs": KNOWN}
+    # entries this script does not produce (the pinned checksums of the benchmark frames, written when those frames
+    # were checked against the oracle) are carried over from the existing file
+    try:
+        with open(os.path.join(HERE, "golden.json")) as f:
+            for key, value in json.load(f).items():
+                golden.setdefault(key, value)
+    except OSError:
+        pass
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(golden, f, indent=1, sort_keys=True)
         f.write("\n")

@@ -433,6 +433,47 @@ def test_primary_pass_in_units_drawn_while_it_runs(gpu, oracle_frame):
     assert frames[0]["stats"]["rays_per_generation"] == frames[1]["stats"]["rays_per_generation"]
 
 
+def test_stale_ring_words_are_not_taken_for_the_awaited_unit(gpu, oracle_frame):
+    """The hand-over of units inside a block goes through four LDS words tagged with the unit's place in the block's
+    sequence.  LDS keeps what the last block on a compute unit left there; with the option `ring_poison` a launch before
+    every such primary pass fills those words, on every compute unit, with exactly the tags the pass's blocks will wait
+    for and the number of a unit that is not theirs.  A pass that took such a word for the awaited one would trace that
+    unit instead of its own: wrong hit map, wrong ray counts, on the first frame."""
+    scene, res, n = "teapot-3", (2048, 1040), 2
+    s = load_scene(gpu, scene)
+    cam = s.camera(*res)
+    gpu.set_option("ring_poison", 1)
+    try:
+        g = gpu.render(cam, num_samples=n, flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    finally:
+        gpu.set_option("ring_poison", 0)
+    o = oracle_frame(scene, res=res, num_samples=n)
+    assert g["stats"]["queue_overflow"] == 0
+    assert_frames_match(g, o, tol=1e-6)
+    assert g["stats"]["closest_rays"] == o["counters"]["closest_rays"]
+    assert g["stats"]["shadow_rays"] == o["counters"]["shadow_rays"]
+
+
+def test_host_built_light_camera_trees_give_the_same_frame(gpu, oracle_frame):
+    """The light cameras' point octrees are built on the device; the host builder with the same rules (Octree.h:1394-1497)
+    stays behind the option `lightcam_host`.  glass.nff with it: the reference's own hide.ppm again."""
+    import gzip
+    import os
+    s = load_scene(gpu, "glass")
+    gpu.set_option("lightcam_host", 1)       # (drops the cameras the context holds; they are set up again on demand)
+    try:
+        g = gpu.render(s.camera(), flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    finally:
+        gpu.set_option("lightcam_host", 0)
+    o = oracle_frame("glass")
+    assert_frames_match(g, o, tol=1e-6)
+    assert g["stats"]["lightcam_rays"] == sum(c["light_rays"] for c in o["lightcams"])
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hide.ppm.gz"), "rb") as f:
+        ref = f.read()
+    golden = np.frombuffer(ref[len(b"P6\n900 900\n255\n"):], dtype=np.uint8).reshape(900, 900, 3)
+    assert np.array_equal(g["rgb_u8"], golden)
+
+
 @pytest.mark.parametrize("scene", ["glass3", "glass"])
 def test_one_launch_kernel_with_light_cameras(gpu, oracle_frame, scene):
     s = load_scene(gpu, scene)

@@ -52,6 +52,15 @@ def test_noalloc_equals_render_async_on_two_calls_in_a_row():
     gpu.upload(s2)
     _both(gpu, s2.camera(200, 200), num_samples=2, seed=3)
     _both(gpu, s2.camera(200, 200), band_rows=16, n_parts=3, part=1)
+    # it allocates nothing: the device's free memory is the same before and after calls of different sizes (the
+    # output buffers are made first; hipMemGetInfo sees every hipMalloc of the process, the library's included)
+    cams = [s2.camera(200, 200), s2.camera(64, 48), s2.camera(300, 200)]
+    outs = [_device_frame(c) for c in cams]
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for c, o in zip(cams, outs):
+        gpu.render_noalloc(c, rgb_f64_ptr=o[0].data_ptr(), rgb_u8_ptr=o[1].data_ptr(), hit_id_ptr=o[2].data_ptr())
+    assert torch.cuda.mem_get_info()[0] == free_before
     # light cameras: refused until they exist (building them allocates), then served from the scratch as well
     s3 = rt.Scene.load("glass3")
     gpu.upload(s3)
