@@ -6,6 +6,7 @@
 #include "../../include/raytracer_amd.h"
 #include "accel_build.hpp"
 #include "lightcam_build.hpp"
+#include "viewgrid.hpp"
 
 struct alignas(16) RayRec {      // 80 bytes
     double o[3];
@@ -70,6 +71,11 @@ struct DevScene {
     float bvh_bound;                      // largest |coordinate| of any hierarchy box
     int32_t shade_bounded;                // every material and light coefficient is finite and below 1e100 in magnitude: a Phong
                                           //   factor of zero then makes the whole term zero (no infinity times zero)
+    // grids of what each light can see (viewgrid.hpp, grid_query.hpp): light l's bins are lg_begin[l * 6 * lg_res^2 ...], a bin's
+    // entries lg_entries[lg_begin[bin] .. lg_begin[bin + 1]); null: shadow queries walk the hierarchies
+    const uint32_t *lg_begin;
+    const vg::Entry *lg_entries;
+    int32_t lg_res;
     // light cameras (LightCam.h): one per (transparent sphere, light) pair, index rank*n_lights+light
     const int32_t *prim_lc_rank;          // per primitive: rank among transparent spheres, or -1
     const rt_sph_rec *tsph;               // the transparent spheres, by rank, and their primitive ids: the only
@@ -130,6 +136,10 @@ struct FrameParams {
     double *accum;               // local_rows*resx*3
     int32_t *hit_id;             // local_rows*resx or null
     uint8_t *lc_mask;            // local_rows*resx or null
+    // grid of what the eye can see, in tiles of 8 x 8 pixels of the whole frame (viewgrid.hpp); null: primary rays walk the hierarchies
+    const uint32_t *cg_begin;
+    const vg::Entry *cg_entries;
+    int32_t cg_tiles_x;
 };
 
 // Queues are cut into N_SHARDS independent shards (a block pushes into shard blockIdx % N_SHARDS),

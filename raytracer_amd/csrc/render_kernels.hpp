@@ -10,6 +10,7 @@
 //   k_debug_intersect   one primitive test per thread (rt_debug_intersect)
 #pragma once
 #include "hierarchy_walk.hpp"
+#include "grid_query.hpp"
 #include "lightcam_query.hpp"
 #include "octree_walk.hpp"
 #include "queues.hpp"
@@ -34,7 +35,7 @@ DEV void camera_to_lds(const FrameParams &P)
 // Positions are counted from the batch's first block, which keeps them in 32 bits, and every
 // division is by a number fixed for the launch (a multiplication, see FastDiv).
 DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, int lane, bool *active_out, d3 *o_out, d3 *d_out,
-                     uint32_t *pixel_out, bool *first_out)
+                     uint32_t *pixel_out, bool *first_out, uint32_t *tile_out)
 {
     const int N = P.N;
     const uint32_t rel = (uint32_t)chunk * 64u + (uint32_t)lane;
@@ -53,6 +54,7 @@ DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, i
     *active_out = j < P.cam.resx && lrow < P.local_rows;
     const int i = global_row(P, lrow);
     *pixel_out = (uint32_t)lrow * (uint32_t)P.cam.resx + (uint32_t)j;
+    *tile_out = ((uint32_t)i >> 3) * (uint32_t)P.cg_tiles_x + ((uint32_t)j >> 3);      // the sample's 8 x 8-pixel tile of the whole frame
     *first_out = (si == 0 && sj == 0);
     struct { double d, l, t, pix_width; int resx; } c;
     d3 u, v, w, e;
@@ -117,10 +119,10 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     bool active;
     d3 o, d;
     double A = 1.0, coef = 1.0;
-    uint32_t pixel = 0, meta = 5u | 0x100u;
+    uint32_t pixel = 0, meta = 5u | 0x100u, tile = 0;
     bool first_sample = false;
     if (PRIMARY) {
-        primary_ray(P, Q, chunk, lane, &active, &o, &d, &pixel, &first_sample);
+        primary_ray(P, Q, chunk, lane, &active, &o, &d, &pixel, &first_sample, &tile);
     } else {
         int shard;
         const int local = shard_locate(smap, (uint32_t)chunk, &shard);
@@ -145,10 +147,16 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
             Best bst;
             bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1; bst.prim = -1;
             if (root_gate(P.S, o, d, d2, 10000000000.0)) {
-                const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
                 WC_ADD(wc, rays);
-                bvh_closest<true>(P.S, o, d, d2, rb, bst, stack, wc);
-                bvh_closest<false>(P.S, o, d, d2, rb, bst, stack, wc);
+                if (PRIMARY && P.cg_begin) {
+                    // every primary ray of a pinhole frame starts at the eye: the list of the sample's 8 x 8-pixel tile holds
+                    // all it can meet (grid_query.hpp)
+                    grid_closest(P.S, P.cg_entries, P.cg_begin[tile], P.cg_begin[tile + 1], o, d, d2, bst, wc);
+                } else {
+                    const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
+                    bvh_closest<true>(P.S, o, d, d2, rb, bst, stack, wc);
+                    bvh_closest<false>(P.S, o, d, d2, rb, bst, stack, wc);
+                }
             }
             best_t = bst.t;
             best = bst.slot;
@@ -461,10 +469,17 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
             }
             occluded = dark;
             if (!dark && root_gate(P.S, Pt, rd, d2, 10000000.0)) {
-                const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
                 WC_ADD(wc, rays);
-                occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc) ||
-                           bvh_any<false>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc);
+                if (P.S.lg_begin) {
+                    // every shadow ray towards this light ends at it: the list of the direction's bin on the light's cube map
+                    // holds all that can lie in between (grid_query.hpp)
+                    const uint32_t bin = (uint32_t)li * 6u * (uint32_t)(P.S.lg_res * P.S.lg_res) + light_bin(Pt, lpos, P.S.lg_res);
+                    occluded = grid_any(P.S, P.S.lg_entries, P.S.lg_begin[bin], P.S.lg_begin[bin + 1], Pt, rd, d2, hit_prim, maxT, wc);
+                } else {
+                    const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
+                    occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc) ||
+                               bvh_any<false>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc);
+                }
             }
         } else if (MODE != SHADOW_BVH) {
             occluded = trace_shadow(P.S, Pt, rd, hit_prim, maxT, cull, &only, &closest);
@@ -806,7 +821,8 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_FUSED) void k_fused(FrameParams P
         bool active, first_sample;
         d3 o, d;
         uint32_t pixel;
-        primary_ray(P, Q, chunk, lane, &active, &o, &d, &pixel, &first_sample);
+        uint32_t tile_unused;
+        primary_ray(P, Q, chunk, lane, &active, &o, &d, &pixel, &first_sample, &tile_unused);
         double A = 1.0, coef = 1.0;
         uint32_t meta = 5u | 0x100u;
         bool have = active, primary = true;

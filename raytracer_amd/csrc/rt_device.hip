@@ -29,6 +29,7 @@
 #include "lightcam_build.hpp"
 #include "render_kernels.hpp"
 #include "lightcam_device.hpp"
+#include "viewgrid.hpp"
 #include <hipcub/hipcub.hpp>
 
 // ------------------------------------------------------------------ errors
@@ -92,6 +93,9 @@ struct DebugOptions {
     int units = 1;                  // 0: the primary pass never shares its chunks out on the device (every block keeps to a fixed share)
     int overlap = -1;               // 1: shadow passes on the second stream beside the next closest-hit pass, 0: one stream, -1: by batch size
     int pair = -1;                  // 1: shadow pass g and closest-hit pass g+1 in one launch, 0: a launch each, -1: default (paired)
+    int grid = 1;                   // 0: no grids, every query walks the hierarchies; 1: lights' and eye's grids (viewgrid.hpp); 2: lights only; 3: eye only
+    int grid_res = 0;               // bins per edge of a face of a light's cube map (0: default)
+    long long grid_min_samples = -1; // the eye's grid is made for frames of at least this many samples (-1: default)
     int ring_poison = 0;            // 1: before a primary pass that hands out units, the LDS ring words of every compute unit are filled with
                                     //    matching tags and wrong unit numbers (k_poison_ring): a deterministic form of what stale LDS can hold
     int lightcam_pool = LC_POOL;    // places used of a wave's pool of pending cells in the light-camera density pass (128..LC_POOL)
@@ -157,6 +161,15 @@ struct rt_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_closest, ev_shadow, ev_pair;
     size_t ev_closest_used = 0, ev_shadow_used = 0, ev_pair_used = 0;
     int pending_closest_per_batch = 6;     // closest-hit launches per batch of the frame in flight (1 when passes are paired)
+    // grids of what a point can see (viewgrid.hpp)
+    int32_t *grid_tri_index = nullptr; int32_t n_grid_tri = 0, n_grid_sph = 0;   // the leaf triangle records to enter: one per primitive
+    uint32_t *lg_begin = nullptr; vg::Entry *lg_entries = nullptr;      // the lights' grids (made at upload; owned by the scene)
+    uint32_t *cg_begin = nullptr; vg::Entry *cg_entries = nullptr;      // the eye's grid: made when a frame's camera differs from the last one's
+    size_t cg_begin_words = 0, cg_entries_words = 0;
+    rt_camera cg_cam{};
+    bool cg_valid = false;
+    int32_t cg_tiles_x = 0;
+    void *grid_ws = nullptr; size_t grid_ws_bytes = 0;        // work space of the grid builder (grow-only)
     int cu_count = 256;
     int32_t n_materials = 0;
     size_t lds_per_cu = 64 * 1024;   // LDS of one compute unit (maxSharedMemoryPerMultiProcessor)
@@ -178,6 +191,10 @@ static void free_lightcams(rt_ctx *ctx)
 static int free_scene(rt_ctx *ctx)
 {
     free_lightcams(ctx);
+    (void)hipFree(ctx->lg_begin); ctx->lg_begin = nullptr;
+    (void)hipFree(ctx->lg_entries); ctx->lg_entries = nullptr;
+    ctx->grid_tri_index = nullptr;      // (one of scene_allocs)
+    ctx->cg_valid = false;
     for (void *p : ctx->scene_allocs) (void)hipFree(p);
     ctx->scene_allocs.clear();
     ctx->has_scene = false;
@@ -311,6 +328,9 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     (void)hipFree(ctx->lc_ws);
     (void)hipFree(ctx->lc_photon_ws);
     (void)hipFree(ctx->lc_packed);
+    (void)hipFree(ctx->cg_begin);
+    (void)hipFree(ctx->cg_entries);
+    (void)hipFree(ctx->grid_ws);
     for (void *p : ctx->stage) (void)hipFree(p);
     for (auto &pr : ctx->ev_closest) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : ctx->ev_shadow) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -426,6 +446,8 @@ static int validate_scene(const rt_scene_desc *s)
     return RT_OK;
 }
 
+static int build_light_grids(rt_ctx *ctx, DevScene &D, int n_sph_records);
+
 extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
 {
     if (!ctx || !s) return fail(RT_ERR_INVALID, "rt_upload_scene: null argument");
@@ -528,6 +550,22 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     D.n_nodes = s->n_nodes;
     D.n_lights = s->n_lights;
     D.bg[0] = s->background[0]; D.bg[1] = s->background[1]; D.bg[2] = s->background[2];
+    {
+        // what the view grids enter: every primitive once (a triangle the hierarchy builder cut into pieces has a leaf
+        // record per piece; the first one stands for it), then the lights' grids
+        std::vector<int32_t> first_record;
+        std::vector<uint8_t> seen(static_cast<size_t>(s->n_prims), 0);
+        for (size_t k = 0; k < acc.tri.size(); ++k) {
+            const int32_t p = acc.tri[k].prim;
+            if (!seen[(size_t)p]) { seen[(size_t)p] = 1; first_record.push_back((int32_t)k); }
+        }
+        const int32_t *d_index = nullptr;
+        if ((rc = upload(ctx, first_record.data(), first_record.size(), &d_index)) != RT_OK) return rc;
+        ctx->grid_tri_index = const_cast<int32_t *>(d_index);
+        ctx->n_grid_tri = (int32_t)first_record.size();
+        ctx->n_grid_sph = (int32_t)acc.sph.size();
+        if ((rc = build_light_grids(ctx, D, ctx->n_grid_sph)) != RT_OK) return rc;
+    }
     ctx->S = D;
     ctx->lightcam_samples = s->lightcam_samples;
     ctx->n_materials = s->n_materials;
@@ -937,6 +975,196 @@ static int provide_lightcams(rt_ctx *ctx, uint32_t lc_flags, bool cull, bool may
     return build_lightcams(ctx, missing, lc_flags, cull);
 }
 
+// ------------------------------------------------------------------ view grids
+// Builds the grids described by `builds` (viewgrid.hpp) into one pair of arrays: *begin_out holds total_bins + 1 offsets
+// into *entries_out (which ends with a spare word).  Count pass, prefix sum, fill pass; the stream is drained once in
+// between, when the number of entries is read.  *begin_out / *entries_out are grown when too small (capacities in words).
+#define VG_LARGE_CAP (1u << 18)
+static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> &builds, size_t total_bins, uint32_t **begin_out,
+                            size_t *begin_words, vg::Entry **entries_out, size_t *entries_words, size_t *n_entries_out)
+{
+    const size_t nb = builds.size();
+    size_t scan_bytes = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)(total_bins + 1), st));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_bins = take((total_bins + 1) * 4), o_large = take(nb * VG_LARGE_CAP * 4), o_ctr = take((nb + 1) * 4), o_scan = take(scan_bytes);
+    int rc = ws_ensure(&ctx->grid_ws, &ctx->grid_ws_bytes, off);
+    if (rc != RT_OK) return rc;
+    unsigned char *ws = static_cast<unsigned char *>(ctx->grid_ws);
+    uint32_t *bins = reinterpret_cast<uint32_t *>(ws + o_bins), *large = reinterpret_cast<uint32_t *>(ws + o_large),
+             *ctr = reinterpret_cast<uint32_t *>(ws + o_ctr);
+    if (*begin_words < total_bins + 1) {
+        (void)hipFree(*begin_out); *begin_out = nullptr; *begin_words = 0;
+        HIP_TRY(hipMalloc((void **)begin_out, (total_bins + 1) * 4));
+        *begin_words = total_bins + 1;
+    }
+    HIP_TRY(hipMemsetAsync(bins, 0, (total_bins + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(ctr, 0, (nb + 1) * 4, st));
+    auto launch = [&](bool fill) {
+        for (size_t b = 0; b < nb; ++b) {
+            vg::Build &B = builds[b];
+            B.bins = bins;
+            B.large = large + b * VG_LARGE_CAP;
+            B.n_large = ctr + b;
+            B.large_cap = VG_LARGE_CAP;
+            B.overflow = ctr + nb;
+            B.entries = fill ? *entries_out : nullptr;
+            const long long threads = (long long)(B.n_tri + B.n_sph) * B.n_faces;
+            if (threads <= 0) continue;
+            const unsigned blocks = (unsigned)((threads + 255) / 256);
+            if (fill) {
+                hipLaunchKernelGGL((vg::k_grid_items<true>), dim3(blocks), dim3(256), 0, st, B);
+                hipLaunchKernelGGL((vg::k_grid_large<true>), dim3(2048), dim3(256), 0, st, B);
+            } else {
+                hipLaunchKernelGGL((vg::k_grid_items<false>), dim3(blocks), dim3(256), 0, st, B);
+                hipLaunchKernelGGL((vg::k_grid_large<false>), dim3(2048), dim3(256), 0, st, B);
+            }
+        }
+    };
+    launch(false);
+    HIP_TRY(hipGetLastError());
+    size_t sb = scan_bytes;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws + o_scan, sb, bins, *begin_out, (int)(total_bins + 1), st));
+    uint32_t total = 0, overflow = 0;
+    HIP_TRY(hipMemcpyAsync(&total, *begin_out + total_bins, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&overflow, ctr + nb, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (overflow) return fail(RT_ERR_CAPACITY, "view grids: too many items that cover many bins");
+    if (*entries_words < (size_t)total + 4) {
+        (void)hipFree(*entries_out); *entries_out = nullptr; *entries_words = 0;
+        const size_t want = (size_t)total + (size_t)total / 4 + 1024;
+        HIP_TRY(hipMalloc((void **)entries_out, want * sizeof(vg::Entry)));
+        *entries_words = want;
+    }
+    HIP_TRY(hipMemsetAsync(*entries_out + total, 0, 4 * sizeof(vg::Entry), st));        // the spare entries behind the last one
+    HIP_TRY(hipMemcpyAsync(bins, *begin_out, (total_bins + 1) * 4, hipMemcpyDeviceToDevice, st));
+    launch(true);
+    hipLaunchKernelGGL(vg::k_grid_sort, dim3((unsigned)((total_bins + 255) / 256)), dim3(256), 0, st, *begin_out, (uint32_t)total_bins, *entries_out);
+    HIP_TRY(hipGetLastError());
+    if (n_entries_out) *n_entries_out = total;
+    return RT_OK;
+}
+
+// The frames of a cube map around a point: faces +x, -x, +y, -y, +z, -z; on each the two other coordinates, in axis order,
+// divided by the major one (light_bin in grid_query.hpp looks bins up the same way).
+static void cube_faces(vg::Build &B, int res, uint32_t first_bin)
+{
+    static const double W[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+    static const double U[6][3] = {{0, 1, 0}, {0, 1, 0}, {1, 0, 0}, {1, 0, 0}, {1, 0, 0}, {1, 0, 0}};
+    static const double V[6][3] = {{0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 1, 0}, {0, 1, 0}};
+    B.n_faces = 6;
+    for (int f = 0; f < 6; ++f) {
+        vg::Face &F = B.face[f];
+        for (int k = 0; k < 3; ++k) { F.u[k] = U[f][k]; F.v[k] = V[f][k]; F.w[k] = W[f][k]; }
+        F.x0 = F.y0 = -1.0;
+        F.inv_cell = 0.5 * res;
+        F.nx = F.ny = res;
+        F.first_bin = first_bin + (uint32_t)f * (uint32_t)res * (uint32_t)res;
+        F._pad = 0;
+    }
+}
+
+// The grids of what each light can see, made once per scene (the hierarchies' leaf records are resident already).
+static int build_light_grids(rt_ctx *ctx, DevScene &D, int n_sph_records)
+{
+    D.lg_begin = nullptr; D.lg_entries = nullptr; D.lg_res = 0;
+    const int mode = ctx->dbg.grid;
+    if (!(mode == 1 || mode == 2) || !ctx->accel_usable || D.n_lights < 1 || D.n_lights > 16) return RT_OK;
+    int res = ctx->dbg.grid_res > 0 ? ctx->dbg.grid_res : 256;
+    if (res < 8) res = 8;
+    if (res > 1024) res = 1024;
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<vg::Build> builds((size_t)D.n_lights);
+    const size_t per_light = (size_t)6 * res * res;
+    for (int l = 0; l < D.n_lights; ++l) {
+        vg::Build &B = builds[(size_t)l];
+        std::memset(&B, 0, sizeof B);
+        for (int k = 0; k < 3; ++k) B.origin[k] = ctx->h_lights[(size_t)l].pos[k];
+        // a shadow query ends .01 before the light (Camera.h:404): what it can report lies at least .01 from the light, at a
+        // depth of at least .01 / sqrt(3) on the face of its major axis
+        B.z_near = 0.005;
+        B.margin = 2.0 / 65536.0;
+        cube_faces(B, res, (uint32_t)(per_light * (size_t)l));
+        B.n_tri = ctx->n_grid_tri;
+        B.n_sph = n_sph_records;
+        B.tri_index = ctx->grid_tri_index;
+        B.tri = D.btri;
+        B.sph = D.bsph;
+    }
+    size_t begin_words = 0, entries_words = 0, n_entries = 0;
+    int rc = build_view_grids(ctx, ctx->stream, builds, per_light * (size_t)D.n_lights, &ctx->lg_begin, &begin_words, &ctx->lg_entries,
+                              &entries_words, &n_entries);
+    if (rc != RT_OK) {
+        // (no grids: the hierarchies answer; not an error of the upload)
+        (void)hipFree(ctx->lg_begin); ctx->lg_begin = nullptr;
+        (void)hipFree(ctx->lg_entries); ctx->lg_entries = nullptr;
+        if (rc == RT_ERR_CAPACITY) return RT_OK;
+        return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    D.lg_begin = ctx->lg_begin;
+    D.lg_entries = ctx->lg_entries;
+    D.lg_res = res;
+    if (ctx->dbg.verbose)
+        fprintf(stderr, "[rt] light grids: %d lights x 6 x %d^2 bins, %zu entries (%.2f per bin), %.2f ms\n", D.n_lights, res, n_entries,
+                (double)n_entries / (double)(per_light * (size_t)D.n_lights),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    return RT_OK;
+}
+
+// The grid of what the eye can see, in tiles of 8 x 8 pixels of the whole frame; kept until the camera or the scene changes.
+static int provide_camera_grid(rt_ctx *ctx, const rt_camera *cam, int n_sph_records)
+{
+    if (ctx->cg_valid && std::memcmp(&ctx->cg_cam, cam, sizeof(rt_camera)) == 0) return RT_OK;
+    ctx->cg_valid = false;
+    const int tx = (cam->resx + 7) / 8, ty = (cam->resy + 7) / 8;
+    std::vector<vg::Build> builds(1);
+    vg::Build &B = builds[0];
+    std::memset(&B, 0, sizeof B);
+    for (int k = 0; k < 3; ++k) B.origin[k] = cam->e[k];
+    // A sample's direction is p u + q v - d w with p = l + (column +- half a pixel) pix_width, q = t - (row +- half a pixel)
+    // pix_width (Camera.h:145-188): projected on the plane at distance d along -w, x = p and y = -q, and the tile of pixel
+    // (row, column) is the bin (row / 8, column / 8) of a grid that starts half a pixel before pixel (0, 0).
+    vg::Face &F = B.face[0];
+    for (int k = 0; k < 3; ++k) { F.u[k] = cam->d * cam->u[k]; F.v[k] = -cam->d * cam->v[k]; F.w[k] = -cam->w[k]; }
+    F.x0 = cam->l - 0.5 * cam->pix_width;
+    F.y0 = -cam->t - 0.5 * cam->pix_width;
+    F.inv_cell = 1.0 / (8.0 * cam->pix_width);
+    F.nx = tx; F.ny = ty;
+    F.first_bin = 0;
+    B.n_faces = 1;
+    const double ext_x = 8.0 * cam->pix_width * tx, ext_y = 8.0 * cam->pix_width * ty;
+    B.margin = (ext_x > ext_y ? ext_x : ext_y) / 65536.0;
+    {
+        // a hit lies at least minT = .01 along a unit direction (Camera.h:322): its depth along -w is at least .01 times the
+        // cosine of the widest angle a sample makes with the axis
+        const double px = std::fmax(std::fabs(F.x0), std::fabs(F.x0 + ext_x)), py = std::fmax(std::fabs(F.y0), std::fabs(F.y0 + ext_y));
+        const double cosine = std::fabs(cam->d) / std::sqrt(cam->d * cam->d + px * px + py * py);
+        B.z_near = 0.005 * cosine;
+    }
+    if (!(B.z_near > 0) || !(cam->pix_width > 0) || !(cam->d > 0)) return fail(RT_ERR_UNSUPPORTED, "camera grid: degenerate camera");
+    B.n_tri = ctx->n_grid_tri;
+    B.n_sph = n_sph_records;
+    B.tri_index = ctx->grid_tri_index;
+    B.tri = ctx->S.btri;
+    B.sph = ctx->S.bsph;
+    size_t n_entries = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    int rc = build_view_grids(ctx, ctx->stream, builds, (size_t)tx * ty, &ctx->cg_begin, &ctx->cg_begin_words, &ctx->cg_entries,
+                              &ctx->cg_entries_words, &n_entries);
+    if (rc != RT_OK) return rc;
+    ctx->cg_cam = *cam;
+    ctx->cg_tiles_x = tx;
+    ctx->cg_valid = true;
+    if (ctx->dbg.verbose) {
+        (void)hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[rt] camera grid: %d x %d tiles, %zu entries (%.2f per tile), %.2f ms\n", tx, ty, n_entries,
+                (double)n_entries / ((double)tx * ty), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    }
+    return RT_OK;
+}
+
 // ------------------------------------------------------------------ frame planning
 // Sizes of the sharded queues of one batch.  A block pushes into shard blockIdx % N_SHARDS and the 64-item chunks
 // of a pass are dealt to the blocks in a fixed pattern, so what a shard can receive in a generation follows from
@@ -1266,6 +1494,17 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const size_t lds_closest = lds_bvh;
     const size_t lds_shadow = lds_bvh;
     const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
+    // the eye's grid (viewgrid.hpp): pinhole frames large enough to pay for it (it is kept while the camera stays)
+    P.cg_begin = nullptr; P.cg_entries = nullptr; P.cg_tiles_x = (cam->resx + 7) / 8;
+    {
+        const long long cg_min = ctx->dbg.grid_min_samples >= 0 ? ctx->dbg.grid_min_samples : (1ll << 22);
+        if (bvh_closest_ok && !noalloc && !use_fused && local_rows > 0 && (ctx->dbg.grid == 1 || ctx->dbg.grid == 3) && !(o->aperture > 0) &&
+            (long long)n_pixels * spp >= cg_min) {
+            const int grc = provide_camera_grid(ctx, cam, ctx->n_grid_sph);
+            if (grc == RT_OK) { P.cg_begin = ctx->cg_begin; P.cg_entries = ctx->cg_entries; P.cg_tiles_x = ctx->cg_tiles_x; }
+            else if (grc != RT_ERR_CAPACITY && grc != RT_ERR_UNSUPPORTED) return grc;
+        }
+    }
 
     // ---- queues
     const int rounds = ctx->dbg.rounds > 0 ? ctx->dbg.rounds : 2;        // rounds of resident blocks a queued pass is cut into
@@ -1887,6 +2126,9 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "overlap") ctx->dbg.overlap = (int)value;
     else if (n == "pair") ctx->dbg.pair = (int)value;
     else if (n == "ring_poison") ctx->dbg.ring_poison = value != 0;
+    else if (n == "grid") { ctx->dbg.grid = (int)value; ctx->cg_valid = false; }          // (lights' grids: read at the next upload)
+    else if (n == "grid_res") ctx->dbg.grid_res = (int)value;
+    else if (n == "grid_min_samples") ctx->dbg.grid_min_samples = value;
     else if (n == "lightcam_pool") ctx->dbg.lightcam_pool = value < 128 ? 128 : (value > LC_POOL ? LC_POOL : (int)value);
     else if (n == "queue_growth") ctx->growth = value < 1 ? 1 : (value > 32 ? 32 : (int)value);
     else return fail(RT_ERR_INVALID, "rt_debug_set_option: unknown option '" + n + "'");
