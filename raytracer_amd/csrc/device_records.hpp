@@ -71,9 +71,9 @@ struct DevScene {
     float bvh_bound;                      // largest |coordinate| of any hierarchy box
     int32_t shade_bounded;                // every material and light coefficient is finite and below 1e100 in magnitude: a Phong
                                           //   factor of zero then makes the whole term zero (no infinity times zero)
-    // grids of what each light can see (viewgrid.hpp, grid_query.hpp): light l's bins are lg_begin[l * 6 * lg_res^2 ...], a bin's
-    // entries lg_entries[lg_begin[bin] .. lg_begin[bin + 1]); null: shadow queries walk the hierarchies
-    const uint32_t *lg_begin;
+    // grids of what each light can see (viewgrid.hpp, grid_query.hpp): light l's bins are lg_bins[l * 6 * lg_res^2 ...], a bin's
+    // list lies in lg_entries; null: shadow queries walk the hierarchies
+    const vg::Bin *lg_bins;
     const vg::Entry *lg_entries;
     int32_t lg_res;
     // light cameras (LightCam.h): one per (transparent sphere, light) pair, index rank*n_lights+light
@@ -137,7 +137,7 @@ struct FrameParams {
     int32_t *hit_id;             // local_rows*resx or null
     uint8_t *lc_mask;            // local_rows*resx or null
     // grid of what the eye can see, in tiles of 8 x 8 pixels of the whole frame (viewgrid.hpp); null: primary rays walk the hierarchies
-    const uint32_t *cg_begin;
+    const vg::Bin *cg_bins;
     const vg::Entry *cg_entries;
     int32_t cg_tiles_x;
 };

@@ -29,22 +29,46 @@ DEV uint32_t light_bin(d3 Pt, d3 L, int res)
 }
 
 typedef uint32_t grid_v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t grid_v4u __attribute__((ext_vector_type(4)));
 
-// Any hit in (minT, maxT) by an entry of entries[begin, end) other than `parent`.  A hit at parameter t lies maxT + .01 - t
+// The entries of one bin in order: the first two come with the bin's head, the others from the list (fetched one ahead).
+struct GridList {
+    const __attribute__((address_space(1))) grid_v2u *rest;     // the list (entry k at rest[k])
+    uint32_t count;
+    grid_v2u cur, after;
+};
+DEV GridList grid_list(const vg::Bin *bins, uint32_t bin, const vg::Entry *entries)
+{
+    const __attribute__((address_space(1))) grid_v4u *h = (const __attribute__((address_space(1))) grid_v4u *)(bins + bin);
+    const grid_v4u a = h[0], b = h[1];
+    GridList l;
+    l.rest = (const __attribute__((address_space(1))) grid_v2u *)entries + a.x;
+    l.count = a.y;
+    l.cur.x = a.z; l.cur.y = a.w;
+    l.after.x = b.x; l.after.y = b.y;
+    return l;
+}
+// entry k is in l.cur; makes entry k + 1 current
+DEV void grid_next(GridList &l, uint32_t k)
+{
+    l.cur = l.after;
+    if (k + 2 < l.count) l.after = l.rest[k + 2];
+}
+
+// Any hit in (minT, maxT) by an entry of the bin's list other than `parent`.  A hit at parameter t lies maxT + .01 - t
 // from the light (the ray is a unit vector towards it, maxT its length less .01), so at most maxT from it: the list is in
 // ascending order of a lower bound of that distance and the loop ends at the first entry beyond.
-DEV bool grid_any(const DevScene &S, const vg::Entry *entries, uint32_t begin, uint32_t end, d3 o, d3 d, double d2, int parent, double maxT,
+DEV bool grid_any(const DevScene &S, const vg::Bin *bins, uint32_t bin, const vg::Entry *entries, d3 o, d3 d, double d2, int parent, double maxT,
                   WalkCount &wc)
 {
     const double minT = .01;
-    const __attribute__((address_space(1))) grid_v2u *ent = (const __attribute__((address_space(1))) grid_v2u *)entries;
     const float far = (float)maxT * (1.0f + 0x1p-16f) + 1e-6f;
     bool hit = false;
-    grid_v2u next = ent[begin];          // (the array ends with spare entries)
-    for (uint32_t k = begin; k < end && !hit; ++k) {
-        const grid_v2u e = next;
-        next = ent[k + 1];
+    GridList l = grid_list(bins, bin, entries);
+    for (uint32_t k = 0; k < l.count && !hit; ++k) {
+        const grid_v2u e = l.cur;
         if (__uint_as_float(e.y) > far) break;
+        grid_next(l, k);
         WC_ADD(wc, lane_prims);
         WC_WAVE(wc, wave_prims);
         if (e.x & GRID_SPHERE) {
@@ -60,18 +84,17 @@ DEV bool grid_any(const DevScene &S, const vg::Entry *entries, uint32_t begin, u
     return hit;
 }
 
-// Nearest hit over entries[begin, end), ties by the records' keys (the reference's visiting order).  The parameter of a
+// Nearest hit over the bin's list, ties by the records' keys (the reference's visiting order).  The parameter of a
 // hit is its distance from the eye (unit direction): an entry whose lower bound lies beyond the nearest hit so far ends
 // the loop (a tie is not beyond).
-DEV void grid_closest(const DevScene &S, const vg::Entry *entries, uint32_t begin, uint32_t end, d3 o, d3 d, double d2, Best &best, WalkCount &wc)
+DEV void grid_closest(const DevScene &S, const vg::Bin *bins, uint32_t bin, const vg::Entry *entries, d3 o, d3 d, double d2, Best &best, WalkCount &wc)
 {
     const double minT = .01, maxT = 10000000000.0;
-    const __attribute__((address_space(1))) grid_v2u *ent = (const __attribute__((address_space(1))) grid_v2u *)entries;
-    grid_v2u next = ent[begin];
-    for (uint32_t k = begin; k < end; ++k) {
-        const grid_v2u e = next;
-        next = ent[k + 1];
+    GridList l = grid_list(bins, bin, entries);
+    for (uint32_t k = 0; k < l.count; ++k) {
+        const grid_v2u e = l.cur;
         if (best.t < maxT && __uint_as_float(e.y) > (float)best.t * (1.0f + 0x1p-16f) + 1e-6f) break;
+        grid_next(l, k);
         WC_ADD(wc, lane_prims);
         WC_WAVE(wc, wave_prims);
         double t;

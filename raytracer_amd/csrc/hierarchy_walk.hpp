@@ -37,12 +37,17 @@ DEV void walk_count_flush(WalkCount &c, int base)
 #define RT_STAMP_WAVES 16384
 #define RT_STAMP_SLOTS 12
 __device__ unsigned long long g_stamps[RT_STAMP_WAVES * RT_STAMP_SLOTS];
-__device__ int g_stamp_select;      // which launches record: kind * 8 + generation (kind 0 closest hit, 1 shadow)
+__device__ unsigned int g_stamp_seen[RT_STAMP_WAVES * RT_STAMP_SLOTS];
+__device__ int g_stamp_select;      // which launches record: kind * 8 + generation (kind 0 closest hit, 1 shadow), + 256 * n: the wave's
+                                    // n-th passage of each point is the one recorded (0: the first chunk of the wave)
 DEV void stamp_at(int k, int sel)
 {
     const unsigned long long w = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (sel == g_stamp_select && (threadIdx.x & 63) == 0 && w < RT_STAMP_WAVES && g_stamps[w * RT_STAMP_SLOTS + k] == 0)
-        g_stamps[w * RT_STAMP_SLOTS + k] = __builtin_amdgcn_s_memrealtime();
+    if (sel == (g_stamp_select & 255) && (threadIdx.x & 63) == 0 && w < RT_STAMP_WAVES) {
+        const unsigned int seen = g_stamp_seen[w * RT_STAMP_SLOTS + k];
+        g_stamp_seen[w * RT_STAMP_SLOTS + k] = seen + 1u;
+        if (seen == (unsigned int)(g_stamp_select >> 8)) g_stamps[w * RT_STAMP_SLOTS + k] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 #define STAMP(k) stamp_at(k, STAMP_SEL)
 #else

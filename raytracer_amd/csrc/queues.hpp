@@ -137,7 +137,11 @@ DEV void accum_add_runs(double *accum, bool in_queue, bool valid, uint32_t pixel
         const double ox = __shfl_down(vx, off), oy = __shfl_down(vy, off), oz = __shfl_down(vz, off);
         if (same) { vx += ox; vy += oy; vz += oz; }
     }
+#ifdef RT_EXP_NOACCUM
+    if (in_queue && head && vx == 123456.789) {
+#else
     if (in_queue && head && (vx != 0.0 || vy != 0.0 || vz != 0.0)) {
+#endif
         unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 0], vx);
         unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 1], vy);
         unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 2], vz);
@@ -149,6 +153,13 @@ DEV void accum_add_runs(double *accum, bool in_queue, bool valid, uint32_t pixel
 // field happens to be used, and the memory pipeline charges per instruction, not per byte
 // (8K x 16 spp frame: 108 -> 97 ms from the stores alone).  (Non-temporal stores were tried for
 // these write-once records and are far slower: 178 ms.)
+//
+// Layout.  The records of a queue lie in groups of 64: piece k of the 64 records of a group side by side (1 KiB), then
+// piece k + 1 of all of them, and so on.  A wave pushes records into consecutive places and reads 64 consecutive ones,
+// so every store and load instruction of a record's piece then moves one or two contiguous runs of up to a kilobyte --
+// whole cache lines -- where records kept whole (64, 80 or 128 bytes each) made every such instruction touch 64
+// separate lines for 16 bytes of each.  Shard capacities and block slices are multiples of 64 records.
+#define REC_PLANE 1024       // bytes from piece k of a record to its piece k + 1
 typedef double rec_v2d __attribute__((ext_vector_type(2)));
 DEV rec_v2d rec_pack(double a, double b) { rec_v2d v; v.x = a; v.y = b; return v; }
 DEV rec_v2d rec_pack_words(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
@@ -158,15 +169,34 @@ DEV rec_v2d rec_pack_words(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
     v.y = __hiloint2double((int)d, (int)c);
     return v;
 }
+// piece 0 of record `rec` of a queue whose records have `pieces` pieces (the queue starts at a multiple of 64 records)
+DEV char *rec_at(const void *queue, size_t rec, uint32_t pieces)
+{
+#ifdef RT_EXP_SMALLQ
+    rec &= 0xffff;
+#endif
+    return (char *)queue + (rec >> 6) * ((size_t)pieces * REC_PLANE) + (rec & 63u) * 16u;
+}
+// pieces first .. first + N - 1 of the record whose piece 0 is at `rec0`
 template <int N>
-DEV void rec_store(void *dst, const rec_v2d (&q)[N])
+DEV void rec_store(char *rec0, int first, const rec_v2d (&q)[N])
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) *(__attribute__((address_space(1))) rec_v2d *)(rec0 + (first + k) * REC_PLANE) = q[k];
+}
+DEV rec_v2d rec_load(const char *rec0, int k)
+{
+    return *(const __attribute__((address_space(1))) rec_v2d *)(rec0 + k * REC_PLANE);
+}
+// piece k of a table entry or of a record that is kept whole (pieces back to back)
+DEV rec_v2d tab_load(const void *src, int k)
+{
+    return ((const __attribute__((address_space(1))) rec_v2d *)src)[k];
+}
+template <int N>
+DEV void tab_store(void *dst, const rec_v2d (&q)[N])
 {
     __attribute__((address_space(1))) rec_v2d *p = (__attribute__((address_space(1))) rec_v2d *)dst;
 #pragma unroll
     for (int k = 0; k < N; ++k) p[k] = q[k];
-}
-// piece k of the record at `src`
-DEV rec_v2d rec_load(const void *src, int k)
-{
-    return ((const __attribute__((address_space(1))) rec_v2d *)src)[k];
 }

@@ -127,7 +127,7 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
         int shard;
         const int local = shard_locate(smap, (uint32_t)chunk, &shard);
         active = local >= 0;
-        const RayRec *rr = &Q.rays_in[active ? (size_t)shard * Q.in_shard_cap + (uint32_t)local : 0];
+        const char *rr = rec_at(Q.rays_in, active ? (size_t)shard * Q.in_shard_cap + (uint32_t)local : 0, 5);
         const rec_v2d r0 = rec_load(rr, 0), r1 = rec_load(rr, 1), r2 = rec_load(rr, 2), r3 = rec_load(rr, 3), r4 = rec_load(rr, 4);
         o = mk3(r0.x, r0.y, r1.x);
         d = mk3(r1.y, r2.x, r2.y);
@@ -148,14 +148,21 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
             bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1; bst.prim = -1;
             if (root_gate(P.S, o, d, d2, 10000000000.0)) {
                 WC_ADD(wc, rays);
-                if (PRIMARY && P.cg_begin) {
+                if (PRIMARY && P.cg_bins) {
                     // every primary ray of a pinhole frame starts at the eye: the list of the sample's 8 x 8-pixel tile holds
                     // all it can meet (grid_query.hpp)
-                    grid_closest(P.S, P.cg_entries, P.cg_begin[tile], P.cg_begin[tile + 1], o, d, d2, bst, wc);
+#ifndef RT_EXP_NOPRIMQUERY
+                    grid_closest(P.S, P.cg_bins, tile, P.cg_entries, o, d, d2, bst, wc);
+#endif
                 } else {
-                    const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
-                    bvh_closest<true>(P.S, o, d, d2, rb, bst, stack, wc);
-                    bvh_closest<false>(P.S, o, d, d2, rb, bst, stack, wc);
+#ifdef RT_EXP_GRIDONLY
+                    if (!PRIMARY)
+#endif
+                    {
+                        const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
+                        bvh_closest<true>(P.S, o, d, d2, rb, bst, stack, wc);
+                        bvh_closest<false>(P.S, o, d, d2, rb, bst, stack, wc);
+                    }
                 }
             }
             best_t = bst.t;
@@ -196,8 +203,13 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     // Queue pushes.  The three reservations (hit record, refraction ray, reflection ray) are made
     // with two atomics -- both kinds of ray go to the same queue -- issued back to back by one lane,
     // so a wave waits for one round trip to the counters instead of three in a row.
+#ifdef RT_EXP_NOPUSH
+    const bool want_hit = hit && P.S.n_lights > 1000;
+    const bool spawn = hit && L > 1000 && !(coef < .01);
+#else
     const bool want_hit = hit && P.S.n_lights > 0;
     const bool spawn = hit && L > 0 && !(coef < .01);       // Camera.h:244-307
+#endif
     const double coef2 = coef * m.Ks;
     const bool want_refr = spawn && m.T > 0;
     const bool want_refl = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
@@ -213,6 +225,15 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
         if (take_h != n_h) atomicAdd(&Q.counts[CNT_PAD_HITS(Q.generation) + shard], take_h - n_h);
         if (take_r != n_a + n_b) atomicAdd(&Q.counts[CNT_PAD_RAYS(Q.generation + 1) + shard], take_r - (n_a + n_b));
     }
+    // While the counters answer (a trip to memory and back), the records' contents are formed: the unit vector to the
+    // ray's origin for the hit record, the directions of the secondary rays.
+    d3 vv = mk3(0, 0, 0), n2 = mk3(0, 0, 0), n3 = mk3(0, 0, 0), dir_a = mk3(0, 0, 0), dir_b = mk3(0, 0, 0);
+    if (want_hit) {
+        vv = unit3(sub3(o, Pt));
+        if (!flat) { n2 = unit3(n); n3 = unit3(n2); }
+    }
+    if (want_refr) dir_a = refract_dir(d, n, m.ior, false);
+    if (want_refl) dir_b = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));      // hr.reflectionDir (Solid.h:121-122), only where a ray follows it
     base_h = (uint32_t)__shfl((int)base_h, 0);
     base_r = (uint32_t)__shfl((int)base_r, 0);
     STAMP(7);
@@ -228,38 +249,36 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
         // the fillers: of a record only the word that marks it is written (at most 63 of either kind, one per lane)
         const uint32_t fill_h = base_h + n_h + (uint32_t)lane, fill_r = base_r + n_a + n_b + (uint32_t)lane;
         if (n_h + (uint32_t)lane < take_h && fill_h < Q.hit_shard_cap) {
-            HitRec *dst = (HitRec *)((char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + fill_h) * Q.hit_stride);
-            ((__attribute__((address_space(1))) rec_v2d *)dst)[3] = rec_pack(0.0, __hiloint2double(-1, (int)HIT_NONE));
+            const rec_v2d q[1] = {rec_pack(0.0, __hiloint2double(-1, (int)HIT_NONE))};
+            rec_store(rec_at(Q.hits, (size_t)shard * Q.hit_shard_cap + fill_h, Q.hit_stride >> 4), 3, q);
         }
-        if (n_a + n_b + (uint32_t)lane < take_r && fill_r < Q.out_shard_cap)
-            ((__attribute__((address_space(1))) rec_v2d *)&Q.rays_out[(size_t)shard * Q.out_shard_cap + fill_r])[4] = rec_pack_words(RAY_NONE, 0u, 0u, 0u);
+        if (n_a + n_b + (uint32_t)lane < take_r && fill_r < Q.out_shard_cap) {
+            const rec_v2d q[1] = {rec_pack_words(RAY_NONE, 0u, 0u, 0u)};
+            rec_store(rec_at(Q.rays_out, (size_t)shard * Q.out_shard_cap + fill_r, 5), 4, q);
+        }
     }
     if (want_hit && slot_h < Q.hit_shard_cap) {
-        const d3 vv = unit3(sub3(o, Pt));
-        HitRec *dst = (HitRec *)((char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + slot_h) * Q.hit_stride);
+        char *dst = rec_at(Q.hits, (size_t)shard * Q.hit_shard_cap + slot_h, Q.hit_stride >> 4);
         // HitRec: P, v, weight, pixel, prim -- and for a hit whose normal is not its primitive's tabulated one
         // (a sphere, interpolated vertex normals) the material and the normal normalised twice and thrice
         const rec_v2d q[4] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, vv.x), rec_pack(vv.y, vv.z),
                               rec_pack(wloc, __hiloint2double(prim, (int)(pixel | (flat ? HIT_FLAT : 0u))))};
-        rec_store(dst, q);
+        rec_store(dst, 0, q);
         if (!flat) {
-            const d3 n2 = unit3(n), n3 = unit3(n2);
             const rec_v2d r[4] = {rec_pack_words(0u, 0u, (uint32_t)mat, 0u), rec_pack(n2.x, n2.y), rec_pack(n2.z, n3.x), rec_pack(n3.y, n3.z)};
-            rec_store(&dst->light, r);
+            rec_store(dst, 4, r);
         }
     }
     if (want_refr && slot_a < Q.out_shard_cap) {
-        const d3 rd = refract_dir(d, n, m.ior, false);
         // RayRec: o, d, A, coef, pixel, meta, pad
-        const rec_v2d q[5] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, rd.x), rec_pack(rd.y, rd.z), rec_pack(A * m.T, m.T * coef),
+        const rec_v2d q[5] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, dir_a.x), rec_pack(dir_a.y, dir_a.z), rec_pack(A * m.T, m.T * coef),
                               rec_pack_words(pixel, (uint32_t)(L - 1) | 0x100u, 0u, 0u)};
-        rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_a], q);
+        rec_store(rec_at(Q.rays_out, (size_t)shard * Q.out_shard_cap + slot_a, 5), 0, q);
     }
     if (want_refl && slot_b < Q.out_shard_cap) {
-        const d3 refl = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));      // hr.reflectionDir (Solid.h:121-122), only where a ray follows it
-        const rec_v2d q[5] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, refl.x), rec_pack(refl.y, refl.z), rec_pack(A, coef2),
+        const rec_v2d q[5] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, dir_b.x), rec_pack(dir_b.y, dir_b.z), rec_pack(A, coef2),
                               rec_pack_words(pixel, (uint32_t)(L - 1), 0u, 0u)};
-        rec_store(&Q.rays_out[(size_t)shard * Q.out_shard_cap + slot_b], q);
+        rec_store(rec_at(Q.rays_out, (size_t)shard * Q.out_shard_cap + slot_b, 5), 0, q);
     }
     if (Q.commit && take_r) {
         // (k_local) the rays are written: count them into the 64-record pieces of the list they lie in, so that a piece
@@ -417,6 +436,23 @@ __global__ __launch_bounds__(RT_BLOCK) void k_poison_ring(int ring_word, uint32_
 // lasts as long as its slowest lane's walk and whole waves lie on the side of an object a light does not reach
 // (512 x 512 frames 1.5 to 5 % faster); over a large frame 8 % of the queries go, the other lanes of their waves walk on
 // all the same, and the test costs what that saves (8K frame: shadow passes 30.9 -> 31.4 ms), so k_shadow asks every light.
+// The two normals a hit is shaded with (normalised twice and three times) and its material: from the record, or, for a
+// triangle shaded with its own normal, from the primitive's table entries.
+DEV void hit_normals(const DevScene &S, const char *hr, bool flat, int prim, rec_v2d &n0, rec_v2d &n1, rec_v2d &n2)
+{
+    if (flat) {
+        const void *src = (const void *)&S.prim_n23[(size_t)prim * 6];
+        n0 = tab_load(src, 0); n1 = tab_load(src, 1); n2 = tab_load(src, 2);
+    } else {
+        n0 = rec_load(hr, 5); n1 = rec_load(hr, 6); n2 = rec_load(hr, 7);
+    }
+}
+DEV int hit_material(const DevScene &S, const char *hr, bool flat, int prim)
+{
+    if (flat) return S.prim_material[prim];
+    return __double2loint(rec_load(hr, 4).y);       // (HitRec::mat: the third word of piece 4)
+}
+
 template <int MODE, bool SKIP_DARK>
 DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &smap, uint32_t nl, long long chunk, int *stack, bool cull,
                       WalkCount &wc)
@@ -425,7 +461,7 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
     int shard, li;
     const int item = shard_locate_by_light(smap, (uint32_t)chunk, P.div_lights, &shard, &li);      // one light per chunk
     const uint32_t h = item >= 0 ? (uint32_t)item : 0u;
-    const HitRec *hr = (const HitRec *)((const char *)Q.hits + ((size_t)shard * Q.hit_shard_cap + h) * Q.hit_stride);
+    const char *hr = rec_at(Q.hits, (size_t)shard * Q.hit_shard_cap + h, Q.hit_stride >> 4);
     // head of the record: P, weight, pixel, prim, material -- four 16-byte pieces fetched together
     const rec_v2d h0 = rec_load(hr, 0), h1 = rec_load(hr, 1), h3 = rec_load(hr, 3);
     const bool active = item >= 0 && ((uint32_t)__double2loint(h3.y) & ~HIT_FLAT) != HIT_NONE;      // (not a record that only fills its chunk up)
@@ -462,23 +498,30 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
             // answer's consequence by zero): such an item counts as shadowed.
             bool dark = false;
             if (SKIP_DARK && P.S.shade_bounded && fabs(weight) < 1e300) {
-                const void *nsrc = hit_flat ? (const void *)&P.S.prim_n23[(size_t)hit_prim * 6] : (const void *)hr->n;
-                const rec_v2d g2 = rec_load(hr, 2), n0 = rec_load(nsrc, 0), n1 = rec_load(nsrc, 1), n2 = rec_load(nsrc, 2);
-                const rt_material m = load_material(P.S, hit_flat ? P.S.prim_material[hit_prim] : hr->mat, true);
+                const rec_v2d g2 = rec_load(hr, 2);
+                rec_v2d n0, n1, n2;
+                hit_normals(P.S, hr, hit_flat, hit_prim, n0, n1, n2);
+                const rt_material m = load_material(P.S, hit_material(P.S, hr, hit_flat, hit_prim), true);
                 dark = light_adds_nothing(m.Kd, m.Ks, m.Shine, mk3(n0.x, n0.y, n1.x), mk3(n1.y, n2.x, n2.y), mk3(h1.y, g2.x, g2.y), rd);
             }
             occluded = dark;
             if (!dark && root_gate(P.S, Pt, rd, d2, 10000000.0)) {
                 WC_ADD(wc, rays);
-                if (P.S.lg_begin) {
+                if (P.S.lg_bins) {
                     // every shadow ray towards this light ends at it: the list of the direction's bin on the light's cube map
                     // holds all that can lie in between (grid_query.hpp)
                     const uint32_t bin = (uint32_t)li * 6u * (uint32_t)(P.S.lg_res * P.S.lg_res) + light_bin(Pt, lpos, P.S.lg_res);
-                    occluded = grid_any(P.S, P.S.lg_entries, P.S.lg_begin[bin], P.S.lg_begin[bin + 1], Pt, rd, d2, hit_prim, maxT, wc);
+#ifdef RT_EXP_NOQUERY
+                    occluded = (bin == 0xffffffffu);
+#else
+                    occluded = grid_any(P.S, P.S.lg_bins, bin, P.S.lg_entries, Pt, rd, d2, hit_prim, maxT, wc);
+#endif
                 } else {
+#ifndef RT_EXP_GRIDONLY
                     const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
                     occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc) ||
                                bvh_any<false>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc);
+#endif
                 }
             }
         } else if (MODE != SHADOW_BVH) {
@@ -504,11 +547,16 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
             const rt_light lgt = load_light(P.S, li, true);     // read again here rather than kept in registers through the walk
             // the view vector from the record; the two normals from the record too, or from the primitive's table
             // entry when they are the flat triangle's own -- four 16-byte pieces fetched together
-            const void *nsrc = hit_flat ? (const void *)&P.S.prim_n23[(size_t)hit_prim * 6] : (const void *)hr->n;
-            const rec_v2d g2 = rec_load(hr, 2), n0 = rec_load(nsrc, 0), n1 = rec_load(nsrc, 1), n2 = rec_load(nsrc, 2);
-            const int hit_mat = hit_flat ? P.S.prim_material[hit_prim] : hr->mat;
+            const rec_v2d g2 = rec_load(hr, 2);
+            rec_v2d n0, n1, n2;
+            hit_normals(P.S, hr, hit_flat, hit_prim, n0, n1, n2);
+            const int hit_mat = hit_material(P.S, hr, hit_flat, hit_prim);
+#ifdef RT_EXP_NOPHONG
+            local = mk3(n0.x + lgt.intensity, n1.y + g2.x, (double)hit_mat);
+#else
             local = phong_terms(load_material(P.S, hit_mat, true), mk3(n0.x, n0.y, n1.x), mk3(n1.y, n2.x, n2.y),
                                 mk3(h1.y, g2.x, g2.y), &lgt, rd, .999999);
+#endif
         }
     }
     if (MODE != SHADOW_BVH && P.S.lc_table) {
@@ -517,12 +565,15 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
         const uint32_t slot = wave_reserve(want, Q.defer_counts ? Q.defer_counts : &Q.counts[CNT_DEFER(Q.generation)], Q.defer_shard_cap,
                                            &Q.counts[CNT_OVERFLOW + 1], &ok);
         if (ok) {
+            // the deferred queue keeps its records whole (k_lightcam reads them field by field)
             HitRec *dr = &Q.deferred[slot];
-            *dr = *hr;
-            dr->pixel = pixel | (hit_flat ? HIT_FLAT : 0u);
-            dr->light = li;
-            dr->cam = defer_cam;
-            if (hit_flat) dr->mat = P.S.prim_material[hit_prim];
+            const rec_v2d g2 = rec_load(hr, 2);
+            const rec_v2d a[4] = {h0, h1, g2, rec_pack(weight, __hiloint2double(hit_prim, (int)(pixel | (hit_flat ? HIT_FLAT : 0u))))};
+            tab_store(dr, a);
+            rec_v2d n0 = rec_pack(0, 0), n1 = n0, n2 = n0;
+            if (!hit_flat) hit_normals(P.S, hr, false, hit_prim, n0, n1, n2);
+            const rec_v2d b[4] = {rec_pack_words((uint32_t)li, (uint32_t)defer_cam, (uint32_t)hit_material(P.S, hr, hit_flat, hit_prim), 0u), n0, n1, n2};
+            tab_store(&dr->light, b);
         } else if (want) {
             Q.counts[CNT_OVERFLOW] = 1u;      // the queue holds every (hit, light) pair of its generation: not expected; reported
         }
@@ -950,7 +1001,7 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_FUSED) void k_fused(FrameParams P
                             d3 na = n2, nb = n3;
                             if (flat) {
                                 const void *nsrc = (const void *)&P.S.prim_n23[(size_t)prim * 6];
-                                const rec_v2d q0 = rec_load(nsrc, 0), q1 = rec_load(nsrc, 1), q2 = rec_load(nsrc, 2);
+                                const rec_v2d q0 = tab_load(nsrc, 0), q1 = tab_load(nsrc, 1), q2 = tab_load(nsrc, 2);
                                 na = mk3(q0.x, q0.y, q1.x); nb = mk3(q1.y, q2.x, q2.y);
                             }
                             local = phong_terms(load_material(P.S, mat, true), na, nb, vv, &lgt, rd, .999999);
@@ -965,10 +1016,10 @@ __global__ __launch_bounds__(256, RT_MIN_WAVES_FUSED) void k_fused(FrameParams P
                             HitRec *dr = &Q.deferred[slot];
                             const rec_v2d q[4] = {rec_pack(Pt.x, Pt.y), rec_pack(Pt.z, vv.x), rec_pack(vv.y, vv.z),
                                                   rec_pack(wloc, __hiloint2double(prim, (int)(pixel | (flat ? HIT_FLAT : 0u))))};
-                            rec_store(dr, q);
+                            tab_store(dr, q);
                             const rec_v2d r[4] = {rec_pack_words((uint32_t)li, (uint32_t)defer_cam, (uint32_t)mat, 0u), rec_pack(n2.x, n2.y),
                                                   rec_pack(n2.z, n3.x), rec_pack(n3.y, n3.z)};
-                            rec_store(&dr->light, r);
+                            tab_store(&dr->light, r);
                         } else if (want) {
                             Q.counts[CNT_OVERFLOW] = 1u;      // queue full: the frame is incomplete and is reported as such
                         }

@@ -163,9 +163,9 @@ struct rt_ctx {
     int pending_closest_per_batch = 6;     // closest-hit launches per batch of the frame in flight (1 when passes are paired)
     // grids of what a point can see (viewgrid.hpp)
     int32_t *grid_tri_index = nullptr; int32_t n_grid_tri = 0, n_grid_sph = 0;   // the leaf triangle records to enter: one per primitive
-    uint32_t *lg_begin = nullptr; vg::Entry *lg_entries = nullptr;      // the lights' grids (made at upload; owned by the scene)
-    uint32_t *cg_begin = nullptr; vg::Entry *cg_entries = nullptr;      // the eye's grid: made when a frame's camera differs from the last one's
-    size_t cg_begin_words = 0, cg_entries_words = 0;
+    vg::Bin *lg_bins = nullptr; vg::Entry *lg_entries = nullptr;      // the lights' grids (made at upload; owned by the scene)
+    vg::Bin *cg_bins = nullptr; vg::Entry *cg_entries = nullptr;      // the eye's grid: made when a frame's camera differs from the last one's
+    size_t cg_bins_cap = 0, cg_entries_words = 0;
     rt_camera cg_cam{};
     bool cg_valid = false;
     int32_t cg_tiles_x = 0;
@@ -191,7 +191,7 @@ static void free_lightcams(rt_ctx *ctx)
 static int free_scene(rt_ctx *ctx)
 {
     free_lightcams(ctx);
-    (void)hipFree(ctx->lg_begin); ctx->lg_begin = nullptr;
+    (void)hipFree(ctx->lg_bins); ctx->lg_bins = nullptr;
     (void)hipFree(ctx->lg_entries); ctx->lg_entries = nullptr;
     ctx->grid_tri_index = nullptr;      // (one of scene_allocs)
     ctx->cg_valid = false;
@@ -328,7 +328,7 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     (void)hipFree(ctx->lc_ws);
     (void)hipFree(ctx->lc_photon_ws);
     (void)hipFree(ctx->lc_packed);
-    (void)hipFree(ctx->cg_begin);
+    (void)hipFree(ctx->cg_bins);
     (void)hipFree(ctx->cg_entries);
     (void)hipFree(ctx->grid_ws);
     for (void *p : ctx->stage) (void)hipFree(p);
@@ -396,6 +396,8 @@ extern "C" int rt_debug_stamps(unsigned long long *out, int n_words)
     void *p = nullptr;
     HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)));
     HIP_TRY(hipMemset(p, 0, sizeof(unsigned long long) * RT_STAMP_WAVES * RT_STAMP_SLOTS));
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamp_seen)));
+    HIP_TRY(hipMemset(p, 0, sizeof(unsigned int) * RT_STAMP_WAVES * RT_STAMP_SLOTS));
     return RT_OK;
 }
 #endif
@@ -976,28 +978,29 @@ static int provide_lightcams(rt_ctx *ctx, uint32_t lc_flags, bool cull, bool may
 }
 
 // ------------------------------------------------------------------ view grids
-// Builds the grids described by `builds` (viewgrid.hpp) into one pair of arrays: *begin_out holds total_bins + 1 offsets
-// into *entries_out (which ends with a spare word).  Count pass, prefix sum, fill pass; the stream is drained once in
-// between, when the number of entries is read.  *begin_out / *entries_out are grown when too small (capacities in words).
+// Builds the grids described by `builds` (viewgrid.hpp) into one pair of arrays: *bins_out holds the total_bins bin heads,
+// *entries_out the lists (it ends with spare entries).  Count pass, prefix sum, fill pass, sort, heads; the stream is
+// drained once in between, when the number of entries is read.  *bins_out / *entries_out are grown when too small.
 #define VG_LARGE_CAP (1u << 18)
-static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> &builds, size_t total_bins, uint32_t **begin_out,
-                            size_t *begin_words, vg::Entry **entries_out, size_t *entries_words, size_t *n_entries_out)
+static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> &builds, size_t total_bins, vg::Bin **bins_out,
+                            size_t *bins_cap, vg::Entry **entries_out, size_t *entries_words, size_t *n_entries_out)
 {
     const size_t nb = builds.size();
     size_t scan_bytes = 0;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)(total_bins + 1), st));
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_bins = take((total_bins + 1) * 4), o_large = take(nb * VG_LARGE_CAP * 4), o_ctr = take((nb + 1) * 4), o_scan = take(scan_bytes);
+    const size_t o_bins = take((total_bins + 1) * 4), o_begin = take((total_bins + 1) * 4), o_large = take(nb * VG_LARGE_CAP * 4), o_ctr = take((nb + 1) * 4), o_scan = take(scan_bytes);
     int rc = ws_ensure(&ctx->grid_ws, &ctx->grid_ws_bytes, off);
     if (rc != RT_OK) return rc;
     unsigned char *ws = static_cast<unsigned char *>(ctx->grid_ws);
     uint32_t *bins = reinterpret_cast<uint32_t *>(ws + o_bins), *large = reinterpret_cast<uint32_t *>(ws + o_large),
              *ctr = reinterpret_cast<uint32_t *>(ws + o_ctr);
-    if (*begin_words < total_bins + 1) {
-        (void)hipFree(*begin_out); *begin_out = nullptr; *begin_words = 0;
-        HIP_TRY(hipMalloc((void **)begin_out, (total_bins + 1) * 4));
-        *begin_words = total_bins + 1;
+    uint32_t *begin = reinterpret_cast<uint32_t *>(ws + o_begin);
+    if (*bins_cap < total_bins) {
+        (void)hipFree(*bins_out); *bins_out = nullptr; *bins_cap = 0;
+        HIP_TRY(hipMalloc((void **)bins_out, total_bins * sizeof(vg::Bin)));
+        *bins_cap = total_bins;
     }
     HIP_TRY(hipMemsetAsync(bins, 0, (total_bins + 1) * 4, st));
     HIP_TRY(hipMemsetAsync(ctr, 0, (nb + 1) * 4, st));
@@ -1025,9 +1028,9 @@ static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> 
     launch(false);
     HIP_TRY(hipGetLastError());
     size_t sb = scan_bytes;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws + o_scan, sb, bins, *begin_out, (int)(total_bins + 1), st));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws + o_scan, sb, bins, begin, (int)(total_bins + 1), st));
     uint32_t total = 0, overflow = 0;
-    HIP_TRY(hipMemcpyAsync(&total, *begin_out + total_bins, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&total, begin + total_bins, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&overflow, ctr + nb, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (overflow) return fail(RT_ERR_CAPACITY, "view grids: too many items that cover many bins");
@@ -1038,9 +1041,10 @@ static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> 
         *entries_words = want;
     }
     HIP_TRY(hipMemsetAsync(*entries_out + total, 0, 4 * sizeof(vg::Entry), st));        // the spare entries behind the last one
-    HIP_TRY(hipMemcpyAsync(bins, *begin_out, (total_bins + 1) * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(bins, begin, (total_bins + 1) * 4, hipMemcpyDeviceToDevice, st));
     launch(true);
-    hipLaunchKernelGGL(vg::k_grid_sort, dim3((unsigned)((total_bins + 255) / 256)), dim3(256), 0, st, *begin_out, (uint32_t)total_bins, *entries_out);
+    hipLaunchKernelGGL(vg::k_grid_sort, dim3((unsigned)((total_bins + 255) / 256)), dim3(256), 0, st, begin, (uint32_t)total_bins, *entries_out);
+    hipLaunchKernelGGL(vg::k_grid_heads, dim3((unsigned)((total_bins + 255) / 256)), dim3(256), 0, st, begin, (uint32_t)total_bins, *entries_out, *bins_out);
     HIP_TRY(hipGetLastError());
     if (n_entries_out) *n_entries_out = total;
     return RT_OK;
@@ -1068,7 +1072,7 @@ static void cube_faces(vg::Build &B, int res, uint32_t first_bin)
 // The grids of what each light can see, made once per scene (the hierarchies' leaf records are resident already).
 static int build_light_grids(rt_ctx *ctx, DevScene &D, int n_sph_records)
 {
-    D.lg_begin = nullptr; D.lg_entries = nullptr; D.lg_res = 0;
+    D.lg_bins = nullptr; D.lg_entries = nullptr; D.lg_res = 0;
     const int mode = ctx->dbg.grid;
     if (!(mode == 1 || mode == 2) || !ctx->accel_usable || D.n_lights < 1 || D.n_lights > 16) return RT_OK;
     int res = ctx->dbg.grid_res > 0 ? ctx->dbg.grid_res : 256;
@@ -1092,18 +1096,18 @@ static int build_light_grids(rt_ctx *ctx, DevScene &D, int n_sph_records)
         B.tri = D.btri;
         B.sph = D.bsph;
     }
-    size_t begin_words = 0, entries_words = 0, n_entries = 0;
-    int rc = build_view_grids(ctx, ctx->stream, builds, per_light * (size_t)D.n_lights, &ctx->lg_begin, &begin_words, &ctx->lg_entries,
+    size_t bins_cap = 0, entries_words = 0, n_entries = 0;
+    int rc = build_view_grids(ctx, ctx->stream, builds, per_light * (size_t)D.n_lights, &ctx->lg_bins, &bins_cap, &ctx->lg_entries,
                               &entries_words, &n_entries);
     if (rc != RT_OK) {
         // (no grids: the hierarchies answer; not an error of the upload)
-        (void)hipFree(ctx->lg_begin); ctx->lg_begin = nullptr;
+        (void)hipFree(ctx->lg_bins); ctx->lg_bins = nullptr;
         (void)hipFree(ctx->lg_entries); ctx->lg_entries = nullptr;
         if (rc == RT_ERR_CAPACITY) return RT_OK;
         return rc;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    D.lg_begin = ctx->lg_begin;
+    D.lg_bins = ctx->lg_bins;
     D.lg_entries = ctx->lg_entries;
     D.lg_res = res;
     if (ctx->dbg.verbose)
@@ -1151,7 +1155,7 @@ static int provide_camera_grid(rt_ctx *ctx, const rt_camera *cam, int n_sph_reco
     B.sph = ctx->S.bsph;
     size_t n_entries = 0;
     const auto t_begin = std::chrono::steady_clock::now();
-    int rc = build_view_grids(ctx, ctx->stream, builds, (size_t)tx * ty, &ctx->cg_begin, &ctx->cg_begin_words, &ctx->cg_entries,
+    int rc = build_view_grids(ctx, ctx->stream, builds, (size_t)tx * ty, &ctx->cg_bins, &ctx->cg_bins_cap, &ctx->cg_entries,
                               &ctx->cg_entries_words, &n_entries);
     if (rc != RT_OK) return rc;
     ctx->cg_cam = *cam;
@@ -1495,13 +1499,13 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const size_t lds_shadow = lds_bvh;
     const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
     // the eye's grid (viewgrid.hpp): pinhole frames large enough to pay for it (it is kept while the camera stays)
-    P.cg_begin = nullptr; P.cg_entries = nullptr; P.cg_tiles_x = (cam->resx + 7) / 8;
+    P.cg_bins = nullptr; P.cg_entries = nullptr; P.cg_tiles_x = (cam->resx + 7) / 8;
     {
         const long long cg_min = ctx->dbg.grid_min_samples >= 0 ? ctx->dbg.grid_min_samples : (1ll << 22);
         if (bvh_closest_ok && !noalloc && !use_fused && local_rows > 0 && (ctx->dbg.grid == 1 || ctx->dbg.grid == 3) && !(o->aperture > 0) &&
             (long long)n_pixels * spp >= cg_min) {
             const int grc = provide_camera_grid(ctx, cam, ctx->n_grid_sph);
-            if (grc == RT_OK) { P.cg_begin = ctx->cg_begin; P.cg_entries = ctx->cg_entries; P.cg_tiles_x = ctx->cg_tiles_x; }
+            if (grc == RT_OK) { P.cg_bins = ctx->cg_bins; P.cg_entries = ctx->cg_entries; P.cg_tiles_x = ctx->cg_tiles_x; }
             else if (grc != RT_ERR_CAPACITY && grc != RT_ERR_UNSUPPORTED) return grc;
         }
     }

@@ -39,6 +39,14 @@ struct Entry {
     uint32_t id;
     float depth;
 };
+// What a query reads first of a bin: where its list lies, and the list's first two entries themselves -- most lists are no
+// longer than that, and a query then needs one trip to memory instead of two in a row.
+struct Bin {
+    uint32_t begin, count;
+    Entry first[2];
+    uint32_t _pad[2];
+};
+static_assert(sizeof(Bin) == 32, "a bin head is 32 bytes");
 
 struct Face {
     double u[3], v[3], w[3];       // a point V (relative to the grid's point) with V.w > 0 projects to x = V.u / V.w, y = V.v / V.w
@@ -365,6 +373,21 @@ __global__ __launch_bounds__(256) void k_grid_sort(const uint32_t *begin, uint32
         const Entry t = a[0]; a[0] = a[end]; a[end] = t;
         sift(0, end);
     }
+}
+
+// The bins' heads, from the offsets and the sorted lists.
+__global__ __launch_bounds__(256) void k_grid_heads(const uint32_t *begin, uint32_t n_bins, const Entry *entries, Bin *bins)
+{
+    const uint32_t bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= n_bins) return;
+    Bin b;
+    b.begin = begin[bin];
+    b.count = begin[bin + 1] - b.begin;
+    const Entry none = {0u, 0.0f};
+    b.first[0] = b.count > 0 ? entries[b.begin] : none;
+    b.first[1] = b.count > 1 ? entries[b.begin + 1] : none;
+    b._pad[0] = b._pad[1] = 0u;
+    bins[bin] = b;
 }
 
 }  // namespace vg
