@@ -149,8 +149,9 @@ def measured_counters(workload, kernel, build_id):
     tot = {}
     n = 0
     rd = wr = 0.0
+    prefixes = kernel if isinstance(kernel, (tuple, list)) else (kernel,)
     for name, e in js.items():
-        if name == "_meta" or not name.startswith(kernel) or "hbm_read_bytes_per_launch" not in e:
+        if name == "_meta" or not name.startswith(tuple(prefixes)) or "hbm_read_bytes_per_launch" not in e:
             continue
         n += e["dispatches"]
         rd += e["hbm_read_bytes_per_launch"] * e["dispatches"]
@@ -311,22 +312,27 @@ def main():
                                        lightcam=not (args.flags & rt.FLAG_NO_LIGHTCAM))
         # ---- roofline of the dominant kernel: the one with the largest total time among the launches of a frame
         build_id = rt.build_id()
+        # (kernel names as the profiler prints them, by prefix: the passes that read the view grids are kernels of their own)
+        prefixes = {"k_local / k_fused (the frame is one launch)": ("k_local", "k_fused"),
+                    "primary pass: k_closest<true, true, *>": ("k_closest<true, true",),
+                    "queued closest-hit passes: k_closest<false, true, *>": ("k_closest<false, true",),
+                    "shadow passes: k_shadow<true> / k_shadow_grid": ("k_shadow<true>", "k_shadow_grid")}
         if kt["shadow_launches"] == 0 and kt["closest_launches"] == kt["primary_launches"]:
             classes = {"k_local / k_fused (the frame is one launch)": ("fused", kt["primary_ms"], kt["primary_launches"], kt["closest_rays"] + kt["shadow_rays"])}
         else:
             classes = {
-                "k_closest<true, true>": ("primary", kt["primary_ms"], kt["primary_launches"], kt["primary_rays"]),
-                "k_closest<false, true>": ("queued", kt["closest_ms"] - kt["primary_ms"],
-                                           kt["closest_launches"] - kt["primary_launches"],
-                                           kt["closest_rays"] - kt["primary_rays"]),
-                "k_shadow<true>": ("shadow", kt["shadow_ms"], kt["shadow_launches"], kt["shadow_rays"]),
+                "primary pass: k_closest<true, true, *>": ("primary", kt["primary_ms"], kt["primary_launches"], kt["primary_rays"]),
+                "queued closest-hit passes: k_closest<false, true, *>": ("queued", kt["closest_ms"] - kt["primary_ms"],
+                                                                         kt["closest_launches"] - kt["primary_launches"],
+                                                                         kt["closest_rays"] - kt["primary_rays"]),
+                "shadow passes: k_shadow<true> / k_shadow_grid": ("shadow", kt["shadow_ms"], kt["shadow_launches"], kt["shadow_rays"]),
             }
         kname = max(classes, key=lambda k: classes[k][1])
         dom, ms_total, launches, rays_k = classes[kname]
         launches = max(launches, 1)
         avg_ms = ms_total / launches
         # (for N > 1 the launches, their rays and their times are rank 0's own; the counter passes are one-GPU runs)
-        ctr = measured_counters(args.workload, kname, build_id) if world == 1 else None
+        ctr = measured_counters(args.workload, prefixes[kname], build_id) if world == 1 else None
         stale = ctr.get("stale") if ctr else None
         if stale:
             ctr = None

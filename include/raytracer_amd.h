@@ -226,15 +226,19 @@ int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value);
  * The reference splits the frame over two host threads, rows interleaved (Driver.cpp:377, 735-769).  A group is that
  * split over GPUs: one context per listed device (a device may be listed more than once), the scene replicated, the
  * frame cut into bands of opts->band_rows rows (16 when 0) dealt round-robin to the members, one host thread per
- * member, and the parts gathered on the first device by peer copies and put into frame order.  rt_group_render takes
- * rt_render's arguments (opts->n_parts and opts->part are ignored) and fills frame-order outputs: device memory of the
- * first listed device when out->on_device, else host memory.  stats: ray counts summed, gpu_ms the slowest member's. */
+ * member; as soon as a member's part is rendered, its own device writes the rows into their places of the frame on the
+ * first device through peer access (where two devices cannot reach each other directly: a copy to the first device,
+ * placed there).  rt_group_render takes rt_render's arguments (opts->n_parts and opts->part are ignored) and fills
+ * frame-order outputs: device memory of the first listed device when out->on_device, else host memory.  stats: ray
+ * counts summed, gpu_ms the slowest member's, kernel times and launches (RT_FLAG_TIMING) summed over the members.
+ * rt_group_set_option: "staged" 1 sends every member's part through the copy on the first device (diagnostic). */
 typedef struct rt_group rt_group;
 int rt_group_create(const int *device_ids, int n, rt_group **out);
 int rt_group_destroy(rt_group *g);
 int rt_group_size(const rt_group *g, int *n);
 int rt_group_upload_scene(rt_group *g, const rt_scene_desc *scene);
 int rt_group_render(rt_group *g, const rt_camera *cam, const rt_render_opts *opts, const rt_frame_out *out, rt_stats *stats);
+int rt_group_set_option(rt_group *g, const char *name, int64_t value);
 
 /* Diagnostic: runs the kernels' own primitive tests on n (primitive, ray) pairs, one per GPU thread, so that
  * each can be compared with the reference's function in isolation.

@@ -130,6 +130,7 @@ _SIGNATURES = {
     "rt_group_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "rt_group_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "rt_group_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderOpts), C.POINTER(FrameOut), C.POINTER(Stats)]),
+    "rt_group_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "rt_debug_intersect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.c_double, C.c_double, C.POINTER(C.c_double)]),
     "rth_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -435,6 +436,9 @@ class Group:
 
     def upload(self, scene):
         _check(load().rt_group_upload_scene(self._g, C.byref(scene.desc)))
+
+    def set_option(self, name, value):
+        _check(load().rt_group_set_option(self._g, name.encode(), int(value)))
 
     def render(self, cam, num_samples=1, aperture=0.0, flags=0, seed=0, band_rows=16,
                want=("rgb_f64", "rgb_u8", "hit_id", "lightcam_mask")):

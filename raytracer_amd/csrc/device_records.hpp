@@ -99,6 +99,15 @@ struct DevLightCam {
 // once per compute unit instead of once per 256 threads, which leaves room for four times as much of the
 // scene.  Small frames, which live on latency and on many independent blocks, run 256-thread blocks.
 #define RT_BLOCK 1024
+// Blocks of the kernels that read the view grids only (no hierarchy walk compiled in, no traversal stacks in LDS).  (Ten waves
+// per block, two blocks to a compute unit, five waves per SIMD: measured slower -- the kernels do not fit 96 vector registers
+// without spilling, 8K frame 61.3 ms against 46.9 with sixteen waves of 128 registers; 512-thread blocks 48.1.)
+#ifndef RT_GRID_BLOCK
+#define RT_GRID_BLOCK 1024
+#endif
+#ifndef RT_GRID_WAVES
+#define RT_GRID_WAVES 4
+#endif
 
 // Division of 32-bit unsigned numbers by a divisor fixed per launch, as a multiplication (Granlund and
 // Montgomery's round-up method): for d >= 2 with l = ceil(log2 d), magic = floor(2^32 (2^l - d) / d) + 1 and

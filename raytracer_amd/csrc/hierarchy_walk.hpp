@@ -40,18 +40,41 @@ __device__ unsigned long long g_stamps[RT_STAMP_WAVES * RT_STAMP_SLOTS];
 __device__ unsigned int g_stamp_seen[RT_STAMP_WAVES * RT_STAMP_SLOTS];
 __device__ int g_stamp_select;      // which launches record: kind * 8 + generation (kind 0 closest hit, 1 shadow), + 256 * n: the wave's
                                     // n-th passage of each point is the one recorded (0: the first chunk of the wave)
+// (the stamps of the sampled chunk are kept in LDS and written out when the chunk is over: a stamp that went to memory at
+// once would wait for every memory operation before it and measure that instead)
+DEV unsigned long long *stamp_slots()
+{
+    __shared__ unsigned long long slots[16 * 32];       // per wave: 16 stamps, then 32 passage counters
+    return slots + (threadIdx.x >> 6) * 32;
+}
 DEV void stamp_at(int k, int sel)
 {
     const unsigned long long w = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (sel == (g_stamp_select & 255) && (threadIdx.x & 63) == 0 && w < RT_STAMP_WAVES) {
-        const unsigned int seen = g_stamp_seen[w * RT_STAMP_SLOTS + k];
-        g_stamp_seen[w * RT_STAMP_SLOTS + k] = seen + 1u;
-        if (seen == (unsigned int)(g_stamp_select >> 8)) g_stamps[w * RT_STAMP_SLOTS + k] = __builtin_amdgcn_s_memrealtime();
+        volatile unsigned long long *slot = stamp_slots();
+        volatile unsigned int *seen = reinterpret_cast<volatile unsigned int *>(slot + 16);
+        const unsigned int n = seen[k];
+        seen[k] = n + 1u;
+        if (n == (unsigned int)(g_stamp_select >> 8)) {
+            slot[k] = __builtin_amdgcn_s_memtime();      // shader clock (s_memrealtime takes a microsecond to answer)
+            if (k == 8)
+                for (int j = 0; j < RT_STAMP_SLOTS; ++j) g_stamps[w * RT_STAMP_SLOTS + j] = slot[j];
+        }
+    }
+}
+DEV void stamp_reset()
+{
+    // (at kernel start: LDS keeps what the last block left)
+    if ((threadIdx.x & 63) == 0) {
+        volatile unsigned long long *slot = stamp_slots();
+        for (int j = 0; j < 32; ++j) slot[j] = 0;
     }
 }
 #define STAMP(k) stamp_at(k, STAMP_SEL)
+#define STAMP_RESET() stamp_reset()
 #else
 #define STAMP(k) ((void)0)
+#define STAMP_RESET() ((void)0)
 #endif
 
 // Stack of pending nodes in LDS: entry k of a lane lives at stack[k * block size + thread-in-block] (the walks keep the
@@ -116,6 +139,15 @@ DEV long long next_chunk(const DevScene &S)
     t = __builtin_amdgcn_readfirstlane(t);
     const int shift = S.stack_shift - 6;          // log2 of the waves per block
     return (((long long)blockIdx.x + (long long)gridDim.x * (t >> shift)) << shift) + (t & ((1 << shift) - 1));
+}
+
+// The same ticket for blocks of any number of waves: the block's t-th chunk is chunk blockIdx.x + t * gridDim.x.
+DEV long long next_chunk_strided(const DevScene &S)
+{
+    int t = 0;
+    if ((threadIdx.x & 63) == 0) t = atomicAdd(&s_lds[S.lds_ticket_word], 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    return (long long)blockIdx.x + (long long)gridDim.x * t;
 }
 
 // A 64-byte table entry (rt_material or rt_light) from LDS when it is cached there, else from memory.

@@ -137,11 +137,7 @@ DEV void accum_add_runs(double *accum, bool in_queue, bool valid, uint32_t pixel
         const double ox = __shfl_down(vx, off), oy = __shfl_down(vy, off), oz = __shfl_down(vz, off);
         if (same) { vx += ox; vy += oy; vz += oz; }
     }
-#ifdef RT_EXP_NOACCUM
-    if (in_queue && head && vx == 123456.789) {
-#else
     if (in_queue && head && (vx != 0.0 || vy != 0.0 || vz != 0.0)) {
-#endif
         unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 0], vx);
         unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 1], vy);
         unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 2], vz);
@@ -172,9 +168,6 @@ DEV rec_v2d rec_pack_words(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 // piece 0 of record `rec` of a queue whose records have `pieces` pieces (the queue starts at a multiple of 64 records)
 DEV char *rec_at(const void *queue, size_t rec, uint32_t pieces)
 {
-#ifdef RT_EXP_SMALLQ
-    rec &= 0xffff;
-#endif
     return (char *)queue + (rec >> 6) * ((size_t)pieces * REC_PLANE) + (rec & 63u) * 16u;
 }
 // pieces first .. first + N - 1 of the record whose piece 0 is at `rec0`

@@ -111,11 +111,12 @@ DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, i
 #endif
 // One 64-ray chunk of a closest-hit pass: the rays (generated, or read from the queue), the closest-hit query, the hit
 // record and the pushes of the hit and of the secondary rays.
-template <bool PRIMARY, bool BVH>
+template <bool PRIMARY, bool BVH, bool GRID = false>
 DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &smap, long long chunk, int lane, int *stack, bool cull,
                        WalkCount &wc, uint32_t shard)
 {
 #define STAMP_SEL (Q.generation)
+    STAMP(10);
     bool active;
     d3 o, d;
     double A = 1.0, coef = 1.0;
@@ -148,21 +149,14 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
             bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1; bst.prim = -1;
             if (root_gate(P.S, o, d, d2, 10000000000.0)) {
                 WC_ADD(wc, rays);
-                if (PRIMARY && P.cg_bins) {
+                if (GRID || (PRIMARY && P.cg_bins)) {
                     // every primary ray of a pinhole frame starts at the eye: the list of the sample's 8 x 8-pixel tile holds
                     // all it can meet (grid_query.hpp)
-#ifndef RT_EXP_NOPRIMQUERY
                     grid_closest(P.S, P.cg_bins, tile, P.cg_entries, o, d, d2, bst, wc);
-#endif
-                } else {
-#ifdef RT_EXP_GRIDONLY
-                    if (!PRIMARY)
-#endif
-                    {
-                        const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
-                        bvh_closest<true>(P.S, o, d, d2, rb, bst, stack, wc);
-                        bvh_closest<false>(P.S, o, d, d2, rb, bst, stack, wc);
-                    }
+                } else if (!GRID) {
+                    const RayBox4 rb = make_raybox4(o, d, P.S.bvh_bound);
+                    bvh_closest<true>(P.S, o, d, d2, rb, bst, stack, wc);
+                    bvh_closest<false>(P.S, o, d, d2, rb, bst, stack, wc);
                 }
             }
             best_t = bst.t;
@@ -203,13 +197,8 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     // Queue pushes.  The three reservations (hit record, refraction ray, reflection ray) are made
     // with two atomics -- both kinds of ray go to the same queue -- issued back to back by one lane,
     // so a wave waits for one round trip to the counters instead of three in a row.
-#ifdef RT_EXP_NOPUSH
-    const bool want_hit = hit && P.S.n_lights > 1000;
-    const bool spawn = hit && L > 1000 && !(coef < .01);
-#else
     const bool want_hit = hit && P.S.n_lights > 0;
     const bool spawn = hit && L > 0 && !(coef < .01);       // Camera.h:244-307
-#endif
     const double coef2 = coef * m.Ks;
     const bool want_refr = spawn && m.T > 0;
     const bool want_refl = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
@@ -299,14 +288,16 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
 #undef STAMP_SEL
 }
 
-template <bool PRIMARY, bool BVH>
-__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams P, QueueSet Q)
+// GRID: the primary pass of a frame whose eye has a grid (viewgrid.hpp), as a kernel of its own: no hierarchy walk is
+// compiled in, so it needs no traversal stacks in LDS and fewer registers (blocks of RT_GRID_BLOCK threads).
+template <bool PRIMARY, bool BVH, bool GRID = false>
+__global__ __launch_bounds__(GRID ? RT_GRID_BLOCK : RT_BLOCK, GRID ? RT_GRID_WAVES : RT_MIN_WAVES) void k_closest(FrameParams P, QueueSet Q)
 {
 #define STAMP_SEL (Q.generation)
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k * block size + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
     const int lane = (int)(threadIdx.x & 63);
-    STAMP(0);
+    STAMP_RESET();
     ShardMap smap;
     smap.items = smap.first = smap.total = 0;
     if (!PRIMARY) smap = shard_map(&Q.counts[CNT_RAYS(Q.generation)], Q.in_shard_cap, 1u);
@@ -331,7 +322,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
 #endif
     }
     STAMP(1);
-    fill_node_cache(P.S, BVH);      // ends with the block's barrier
+    fill_node_cache(P.S, BVH);      // (GRID: no nodes are cached, S.tri_cached = S.sph_cached = 0; the leaf records are)      // ends with the block's barrier
     STAMP(2);
     const bool cull = P.cull_closest != 0;
     WalkCount wc{};
@@ -389,10 +380,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void k_closest(FrameParams 
             if (chunk >= n_chunks) continue;
             shard = id & (N_SHARDS - 1);
         } else {
-            chunk = next_chunk(P.S);
+            chunk = (GRID && (RT_GRID_BLOCK & (RT_GRID_BLOCK - 1))) ? next_chunk_strided(P.S) : next_chunk(P.S);
             if (chunk >= n_chunks) break;
         }
-        closest_chunk<PRIMARY, BVH>(P, Q, smap, chunk, lane, stack, cull, wc, shard);
+        closest_chunk<PRIMARY, BVH, GRID>(P, Q, smap, chunk, lane, stack, cull, wc, shard);
     }
     STAMP(9);
 #ifdef RT_COUNT
@@ -453,11 +444,12 @@ DEV int hit_material(const DevScene &S, const char *hr, bool flat, int prim)
     return __double2loint(rec_load(hr, 4).y);       // (HitRec::mat: the third word of piece 4)
 }
 
-template <int MODE, bool SKIP_DARK>
+template <int MODE, bool SKIP_DARK, bool GRID = false>
 DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &smap, uint32_t nl, long long chunk, int *stack, bool cull,
                       WalkCount &wc)
 {
 #define STAMP_SEL (8 + Q.generation)
+    STAMP(10);
     int shard, li;
     const int item = shard_locate_by_light(smap, (uint32_t)chunk, P.div_lights, &shard, &li);      // one light per chunk
     const uint32_t h = item >= 0 ? (uint32_t)item : 0u;
@@ -474,6 +466,9 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
     bool lit = false;
     int defer_cam = -1;
     d3 local = mk3(0, 0, 0);
+#ifdef RT_STAMP
+    if (__ballot(active) == 0xdeadbeefull) return;      // (the record has arrived)
+#endif
     STAMP(3);
     if (active) {
         const d3 toL = sub3(lpos, Pt);
@@ -507,21 +502,15 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
             occluded = dark;
             if (!dark && root_gate(P.S, Pt, rd, d2, 10000000.0)) {
                 WC_ADD(wc, rays);
-                if (P.S.lg_bins) {
+                if (GRID || P.S.lg_bins) {
                     // every shadow ray towards this light ends at it: the list of the direction's bin on the light's cube map
                     // holds all that can lie in between (grid_query.hpp)
                     const uint32_t bin = (uint32_t)li * 6u * (uint32_t)(P.S.lg_res * P.S.lg_res) + light_bin(Pt, lpos, P.S.lg_res);
-#ifdef RT_EXP_NOQUERY
-                    occluded = (bin == 0xffffffffu);
-#else
                     occluded = grid_any(P.S, P.S.lg_bins, bin, P.S.lg_entries, Pt, rd, d2, hit_prim, maxT, wc);
-#endif
-                } else {
-#ifndef RT_EXP_GRIDONLY
+                } else if (!GRID) {
                     const RayBox4 rb = make_raybox4(Pt, rd, P.S.bvh_bound);
                     occluded = bvh_any<true>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc) ||
                                bvh_any<false>(P.S, Pt, rd, d2, rb, hit_prim, maxT, stack, wc);
-#endif
                 }
             }
         } else if (MODE != SHADOW_BVH) {
@@ -551,12 +540,8 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
             rec_v2d n0, n1, n2;
             hit_normals(P.S, hr, hit_flat, hit_prim, n0, n1, n2);
             const int hit_mat = hit_material(P.S, hr, hit_flat, hit_prim);
-#ifdef RT_EXP_NOPHONG
-            local = mk3(n0.x + lgt.intensity, n1.y + g2.x, (double)hit_mat);
-#else
             local = phong_terms(load_material(P.S, hit_mat, true), mk3(n0.x, n0.y, n1.x), mk3(n1.y, n2.x, n2.y),
                                 mk3(h1.y, g2.x, g2.y), &lgt, rd, .999999);
-#endif
         }
     }
     if (MODE != SHADOW_BVH && P.S.lc_table) {
@@ -578,13 +563,17 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
             Q.counts[CNT_OVERFLOW] = 1u;      // the queue holds every (hit, light) pair of its generation: not expected; reported
         }
     }
+#ifdef RT_STAMP
+    if (__ballot(lit && local.x > 1e300) == 0xdeadbeefull) return;      // (the terms are formed)
+#endif
+    STAMP(5);
     accum_add_runs(P.accum, active, lit, pixel, weight, local);
     STAMP(8);
 
 #undef STAMP_SEL
 }
 
-template <int MODE>
+template <int MODE, bool GRID = false>
 DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
 {
     constexpr bool BVH = MODE != SHADOW_EXACT;      // the hierarchies (and their LDS stacks and node cache) are in use
@@ -595,17 +584,18 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
     // traversal stack, sized at launch to the hierarchies' depth (entry k of a thread at [k * block size + thread])
     int *stack = &s_lds[BVH ? threadIdx.x : 0];
     const uint32_t nl = (uint32_t)P.S.n_lights;
-    STAMP(0);
+    STAMP_RESET();
     // work items are (hit, light) pairs: per 64 hits of a shard one chunk for each light
     const ShardMap smap = shard_map_by_light(&Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, nl);
     if ((long long)blockIdx.x * (blockDim.x >> 6) >= (long long)smap.total) return;   // no chunk for this block
     STAMP(1);
-    fill_node_cache(P.S, BVH);
+    fill_node_cache(P.S, BVH);      // (GRID: no nodes are cached, S.tri_cached = S.sph_cached = 0; the leaf records are)
     STAMP(2);
     const bool cull = P.cull_shadow != 0;
     WalkCount wc{};
-    for (long long chunk = next_chunk(P.S); chunk < (long long)smap.total; chunk = next_chunk(P.S)) {
-        shadow_chunk<MODE, false>(P, Q, smap, nl, chunk, stack, cull, wc);
+    for (long long chunk = (GRID && (RT_GRID_BLOCK & (RT_GRID_BLOCK - 1))) ? next_chunk_strided(P.S) : next_chunk(P.S); chunk < (long long)smap.total;
+         chunk = GRID ? next_chunk_strided(P.S) : next_chunk(P.S)) {
+        shadow_chunk<MODE, false, GRID>(P, Q, smap, nl, chunk, stack, cull, wc);
     }
     STAMP(9);
 #ifdef RT_COUNT
@@ -625,6 +615,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_shadow(FrameP
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_SHADOW) void k_shadow_hybrid(FrameParams P, QueueSet Q)
 {
     shadow_pass<SHADOW_HYBRID>(P, Q);
+}
+// The shadow pass of a scene whose lights have grids and whose queries are order-free, as a kernel of its own (see k_closest, GRID).
+__global__ __launch_bounds__(RT_GRID_BLOCK, RT_GRID_WAVES) void k_shadow_grid(FrameParams P, QueueSet Q)
+{
+    shadow_pass<SHADOW_BVH, true>(P, Q);
 }
 
 

@@ -94,6 +94,7 @@ struct DebugOptions {
     int overlap = -1;               // 1: shadow passes on the second stream beside the next closest-hit pass, 0: one stream, -1: by batch size
     int pair = -1;                  // 1: shadow pass g and closest-hit pass g+1 in one launch, 0: a launch each, -1: default (paired)
     int grid = 1;                   // 0: no grids, every query walks the hierarchies; 1: lights' and eye's grids (viewgrid.hpp); 2: lights only; 3: eye only
+    int grid_kernels = 1;           // 0: the passes that read the grids run in the general kernels (1024-thread blocks)
     int grid_res = 0;               // bins per edge of a face of a light's cube map (0: default)
     long long grid_min_samples = -1; // the eye's grid is made for frames of at least this many samples (-1: default)
     int ring_poison = 0;            // 1: before a primary pass that hands out units, the LDS ring words of every compute unit are filled with
@@ -291,7 +292,7 @@ static int create_resources(rt_ctx *ctx, int device_id, const hipDeviceProp_t &p
                                  (const void *)k_local<SHADOW_BVH>, (const void *)k_local<SHADOW_HYBRID>,
                                  (const void *)k_fused<true, SHADOW_BVH>, (const void *)k_fused<true, SHADOW_HYBRID>,
                                  (const void *)k_fused<true, SHADOW_EXACT>, (const void *)k_fused<false, SHADOW_EXACT>,
-                                 (const void *)k_poison_ring};
+                                 (const void *)k_poison_ring, (const void *)k_closest<true, true, true>, (const void *)k_shadow_grid};
         for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     }
     if (device_id < RT_MAX_DEVICES) {
@@ -1509,6 +1510,28 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             else if (grc != RT_ERR_CAPACITY && grc != RT_ERR_UNSUPPORTED) return grc;
         }
     }
+    // The kernels that only read the grids (k_closest<.., GRID>, k_shadow_grid) run in blocks of RT_GRID_BLOCK threads; their
+    // LDS holds the leaf triangle records and the tables, no traversal stacks and no nodes.
+    FrameParams Pg = P;      // (its output pointers follow below, once P has them)
+    size_t lds_grid = 0;
+    const int grid_blocks_per_cu = RT_GRID_BLOCK <= 512 ? 1024 / RT_GRID_BLOCK : (RT_GRID_BLOCK <= 640 ? 2 : 1);
+    {
+        const size_t per_block = ctx->lds_per_cu / grid_blocks_per_cu;
+        const size_t fixed = lds_tables + 128 + 512;
+        long long tc = per_block > fixed ? (long long)((per_block - fixed) / 80) : 0;
+        if (tc > ctx->n_btri) tc = ctx->n_btri;
+        if (ctx->dbg.tri_cache >= 0 && ctx->dbg.tri_cache < tc) tc = ctx->dbg.tri_cache;
+        Pg.S.tri_cached = Pg.S.sph_cached = 0;
+        Pg.S.stack_shift = RT_GRID_BLOCK == 256 ? 8 : (RT_GRID_BLOCK == 512 ? 9 : 10);      // (log2 of the waves per block + 6, for the chunk tickets)
+        Pg.S.lds_cache_word = 0;
+        Pg.S.btri_cached = (int32_t)tc;
+        Pg.S.lds_tri_word = 0;
+        Pg.S.lds_table_word = Pg.S.btri_cached * 20;
+        Pg.S.lds_cam_word = Pg.S.lds_table_word + (Pg.S.mat_cached + Pg.S.light_cached) * 16;
+        Pg.S.lds_ticket_word = Pg.S.lds_cam_word + 32;
+        lds_grid = (size_t)Pg.S.btri_cached * 80 + lds_tables + 128 + 32;
+    }
+    const bool grid_kernels = ctx->dbg.grid_kernels != 0 && block == RT_BLOCK && !noalloc;
 
     // ---- queues
     const int rounds = ctx->dbg.rounds > 0 ? ctx->dbg.rounds : 2;        // rounds of resident blocks a queued pass is cut into
@@ -1708,6 +1731,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
         }
         P.hit_id = static_cast<int32_t *>(dev[2]);
         P.lc_mask = static_cast<uint8_t *>(dev[3]);
+        Pg.accum = P.accum; Pg.hit_id = P.hit_id; Pg.lc_mask = P.lc_mask;
         if (dev[3]) HIP_TRY(hipMemsetAsync(dev[3], 0, bytes[3], st));
 
         // Two streams.  A: counters memset, closest-hit passes C0..C5 of every batch, in order.
@@ -1814,10 +1838,11 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
             if (batch_no >= 2) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_batch[par], 0));
             if (!(batch_no == 0 && counts0_clear)) HIP_TRY(hipMemsetAsync(counts, 0, CNT_WORDS * sizeof(uint32_t), st));
             // (diagnostic, option "ring_poison": see k_poison_ring)
-            auto poison_ring = [&](const QueueSet &Q, uint32_t *cnt) {
+            auto poison_ring = [&](const QueueSet &Q, uint32_t *cnt, bool grid_kernel) {
                 if (!ctx->dbg.ring_poison || !Q.unit_chunks) return;
-                const unsigned resident = (unsigned)(ctx->cu_count * blocks_per_cu);
-                hipLaunchKernelGGL(k_poison_ring, dim3(resident), dim3(block), lds_closest, st, P.S.lds_ticket_word + 4, cnt + CNT_ARRIVED, resident);
+                const unsigned resident = (unsigned)(ctx->cu_count * (grid_kernel ? grid_blocks_per_cu : blocks_per_cu));
+                hipLaunchKernelGGL(k_poison_ring, dim3(resident), dim3(grid_kernel ? RT_GRID_BLOCK : block), grid_kernel ? lds_grid : lds_closest, st,
+                                   (grid_kernel ? Pg.S.lds_ticket_word : P.S.lds_ticket_word) + 4, cnt + CNT_ARRIVED, resident);
             };
             auto queue_set = [&](int g) {
                 QueueSet Q{};
@@ -1862,7 +1887,13 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     if (ev) HIP_TRY(hipEventRecord(ev->first, st));
                     long long blocks = (t1 - t0 + waves_per_block - 1) / waves_per_block;
                     if (blocks > blocks0) blocks = blocks0;
-                    poison_ring(Q, counts);
+                    const bool gk = grid_kernels && P.cg_bins && Q.unit_chunks && bvh_closest_ok;
+                    poison_ring(Q, counts, gk);
+                    if (gk) {
+                        long long gb = (t1 - t0 + RT_GRID_BLOCK / 64 - 1) / (RT_GRID_BLOCK / 64);
+                        if (gb > (long long)ctx->cu_count * grid_blocks_per_cu * rounds) gb = (long long)ctx->cu_count * grid_blocks_per_cu * rounds;
+                        hipLaunchKernelGGL((k_closest<true, true, true>), dim3((unsigned)gb), dim3(RT_GRID_BLOCK), lds_grid, st, Pg, Q);
+                    } else
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                     if (ev) HIP_TRY(hipEventRecord(ev->second, st));
@@ -1930,7 +1961,13 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 if (g == 0) {
                     long long blocks = (t1 - t0 + waves_per_block - 1) / waves_per_block;
                     if (blocks > blocks0) blocks = blocks0;
-                    poison_ring(Q, counts);
+                    const bool gk = grid_kernels && P.cg_bins && Q.unit_chunks && bvh_closest_ok;
+                    poison_ring(Q, counts, gk);
+                    if (gk) {
+                        long long gb = (t1 - t0 + RT_GRID_BLOCK / 64 - 1) / (RT_GRID_BLOCK / 64);
+                        if (gb > (long long)ctx->cu_count * grid_blocks_per_cu * rounds) gb = (long long)ctx->cu_count * grid_blocks_per_cu * rounds;
+                        hipLaunchKernelGGL((k_closest<true, true, true>), dim3((unsigned)gb), dim3(RT_GRID_BLOCK), lds_grid, st, Pg, Q);
+                    } else
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                 } else {
@@ -1945,7 +1982,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     if (timing && !(ev = next_event_pair(ctx->ev_shadow, ctx->ev_shadow_used)))
                         return fail(RT_ERR_DEVICE, "hipEventCreate failed");
                     if (ev) HIP_TRY(hipEventRecord(ev->first, sb));
-                    if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(block), lds_shadow, sb, P, Q);
+                    if (bvh_shadow_ok && grid_kernels && P.S.lg_bins)
+                        hipLaunchKernelGGL(k_shadow_grid, dim3((unsigned)(ctx->cu_count * grid_blocks_per_cu * rounds)), dim3(RT_GRID_BLOCK), lds_grid, sb, Pg, Q);
+                    else if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(block), lds_shadow, sb, P, Q);
                     else if (hybrid_shadow) hipLaunchKernelGGL(k_shadow_hybrid, dim3((unsigned)max_blocks), dim3(block), lds_shadow, sb, P, Q);
                     else hipLaunchKernelGGL((k_shadow<false>), dim3((unsigned)max_blocks), dim3(block), lds_shadow, sb, P, Q);
                     if (ev) HIP_TRY(hipEventRecord(ev->second, sb));
@@ -2132,6 +2171,7 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "ring_poison") ctx->dbg.ring_poison = value != 0;
     else if (n == "grid") { ctx->dbg.grid = (int)value; ctx->cg_valid = false; }          // (lights' grids: read at the next upload)
     else if (n == "grid_res") ctx->dbg.grid_res = (int)value;
+    else if (n == "grid_kernels") ctx->dbg.grid_kernels = (int)value;
     else if (n == "grid_min_samples") ctx->dbg.grid_min_samples = value;
     else if (n == "lightcam_pool") ctx->dbg.lightcam_pool = value < 128 ? 128 : (value > LC_POOL ? LC_POOL : (int)value);
     else if (n == "queue_growth") ctx->growth = value < 1 ? 1 : (value > 32 ? 32 : (int)value);

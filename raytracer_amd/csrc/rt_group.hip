@@ -3,10 +3,13 @@
 // The reference splits a frame over two host threads by interleaving rows (Driver.cpp:377, 735-769).  Here the frame
 // is cut into bands of `band_rows` rows dealt round-robin to the members of a group (band b -> member b % N), every
 // member is an rt_ctx on its own GPU with the scene replicated, and one host thread per member renders its part into a
-// compact buffer on its device.  The only exchange is the end-of-frame gather: each compact buffer goes to the first
-// member's device with one peer copy over xGMI (every peer has its own link to that device, so the copies run side by
-// side), and one kernel per output puts the rows into frame order.  No collective library is involved: a gather to one
-// root over point-to-point links is N-1 independent copies.
+// compact buffer on its device.  The only exchange is the end-of-frame gather, and it has no step of its own: as soon as
+// a member's part is rendered, a kernel on that member's own stream writes its rows straight into their places of the
+// frame on the first member's device, through peer access over xGMI (every peer has its own link to that device, so the
+// members' writes run side by side, and a member that finishes early does not wait for the others).  Only where two
+// devices cannot reach each other directly does a part go through a copy on the first device.  No collective library is
+// involved: a gather to one root over point-to-point links is N-1 independent transfers.  Not run on more than one GPU
+// so far: the tests drive groups of several contexts on one device.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -74,8 +77,12 @@ struct Buffer {
 struct rt_group {
     std::vector<int> devices;
     std::vector<rt_ctx *> ctx;
-    hipStream_t stream = nullptr;                 // on the first member's device: peer copies and row placement
-    // per member and output kind (f64, u8, hit id, mask): the part on the member's device, and its copy on the first device
+    hipStream_t stream = nullptr;                 // on the first member's device: the frame's way to host memory; staged parts
+    std::vector<hipStream_t> mstream;             // per member, on its device: the placement of its rows
+    std::vector<char> direct;                     // per member: its device can write the first device's memory
+    bool force_staged = false;                    // diagnostic: every member's part goes through the copy on the first device
+    // per member and output kind (f64, u8, hit id, mask): the part on the member's device, and (only for a member without
+    // direct access) its copy on the first device
     std::vector<Buffer> part[4], staged[4];
     Buffer frame[4];                              // frame-order outputs on the first device when the caller's buffers are host memory
 };
@@ -92,6 +99,8 @@ extern "C" int rt_group_destroy(rt_group *g)
         g->frame[k].release();
     }
     if (g->stream) { (void)hipSetDevice(g->devices[0]); (void)hipStreamDestroy(g->stream); }
+    for (size_t i = 0; i < g->mstream.size(); ++i)
+        if (g->mstream[i]) { (void)hipSetDevice(g->devices[i]); (void)hipStreamDestroy(g->mstream[i]); }
     delete g;
     return RT_OK;
 }
@@ -112,18 +121,33 @@ extern "C" int rt_group_create(const int *device_ids, int n, rt_group **out)
         rt_group_destroy(g);
         return gfail(RT_ERR_DEVICE, "rt_group_create: no stream on the first device");
     }
-    // direct copies between the members' devices and the first one (ignored where a pair is the same device or already enabled)
-    for (int i = 1; i < n; ++i) {
-        if (device_ids[i] == device_ids[0]) continue;
+    // every member's device gets a stream for placing its rows, and access to the first device's memory (member -> first
+    // device is the direction the rows travel); a member that cannot have it goes through a staged copy instead
+    g->mstream.assign((size_t)n, nullptr);
+    g->direct.assign((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (hipSetDevice(device_ids[i]) != hipSuccess || hipStreamCreateWithFlags(&g->mstream[(size_t)i], hipStreamNonBlocking) != hipSuccess) {
+            rt_group_destroy(g);
+            return gfail(RT_ERR_DEVICE, "rt_group_create: no stream on device " + std::to_string(device_ids[i]));
+        }
+        if (device_ids[i] == device_ids[0]) { g->direct[(size_t)i] = 1; continue; }
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[i]) == hipSuccess && can) {
-            (void)hipSetDevice(device_ids[0]);
-            (void)hipDeviceEnablePeerAccess(device_ids[i], 0);
+        if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[0]) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(device_ids[0], 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) g->direct[(size_t)i] = 1;
             (void)hipGetLastError();
         }
+        // (the staged path copies with hipMemcpyPeerAsync, which needs no access of either side)
     }
     *out = g;
     return RT_OK;
+}
+
+extern "C" int rt_group_set_option(rt_group *g, const char *name, int64_t value)
+{
+    if (!g || !name) return gfail(RT_ERR_INVALID, "rt_group_set_option: null argument");
+    if (std::string(name) == "staged") { g->force_staged = value != 0; return RT_OK; }
+    return gfail(RT_ERR_INVALID, std::string("rt_group_set_option: unknown option '") + name + "'");
 }
 
 extern "C" int rt_group_size(const rt_group *g, int *n)
@@ -177,7 +201,26 @@ extern "C" int rt_group_render(rt_group *g, const rt_camera *cam, const rt_rende
         for (int k = 0; k < 4; ++k)
             if (dst[k] && (rc = g->part[k][i].ensure(g->devices[i], (size_t)rows[i] * cam->resx * kPixelBytes[k])) != RT_OK) return rc;
     }
-    // every member renders its part on a host thread of its own
+    // where the rows go: the caller's device buffers, or frame buffers on the first device on the way to host memory
+    const int d0 = g->devices[0];
+    unsigned char *frame[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t row_bytes[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k) {
+        if (!dst[k]) continue;
+        row_bytes[k] = (size_t)cam->resx * kPixelBytes[k];
+        frame[k] = static_cast<unsigned char *>(dst[k]);
+        if (!out->on_device) {
+            int rc = g->frame[k].ensure(d0, (size_t)cam->resy * row_bytes[k]);
+            if (rc != RT_OK) return rc;
+            frame[k] = static_cast<unsigned char *>(g->frame[k].ptr);
+        }
+        for (int i = 0; i < n; ++i)
+            if ((!g->direct[(size_t)i] || g->force_staged) && rows[i] > 0) {
+                int rc = g->staged[k][i].ensure(d0, (size_t)rows[i] * row_bytes[k]);
+                if (rc != RT_OK) return rc;
+            }
+    }
+    // every member renders its part on a host thread of its own and, when it is done, puts its rows into the frame
     std::vector<rt_stats> ms((size_t)n);
     int rc = for_each_member(g, [&](size_t i) {
         rt_frame_out po = {};
@@ -186,34 +229,33 @@ extern "C" int rt_group_render(rt_group *g, const rt_camera *cam, const rt_rende
         po.hit_id = dst[2] ? g->part[2][i].ptr : nullptr;
         po.lightcam_mask = dst[3] ? g->part[3][i].ptr : nullptr;
         po.on_device = 1;
-        return rt_render(g->ctx[i], cam, &mo[i], &po, &ms[i]);
-    });
-    if (rc != RT_OK) return rc;
-    // gather on the first device: one peer copy per member and output, then the rows into frame order
-    const int d0 = g->devices[0];
-    GHIP(hipSetDevice(d0));
-    for (int k = 0; k < 4; ++k) {
-        if (!dst[k]) continue;
-        const size_t row_bytes = (size_t)cam->resx * kPixelBytes[k];
-        unsigned char *frame = static_cast<unsigned char *>(dst[k]);
-        if (!out->on_device) {
-            if ((rc = g->frame[k].ensure(d0, (size_t)cam->resy * row_bytes)) != RT_OK) return rc;
-            frame = static_cast<unsigned char *>(g->frame[k].ptr);
-        }
-        for (int i = 0; i < n; ++i) {
-            if (rows[i] == 0) continue;
+        int mrc = rt_render(g->ctx[i], cam, &mo[i], &po, &ms[i]);
+        if (mrc != RT_OK || rows[i] == 0) return mrc;
+        const bool direct = g->direct[i] != 0 && !g->force_staged;
+        // direct: the member's own device writes the rows to the first device's memory; else the part is copied to the first
+        // device and placed there
+        GHIP(hipSetDevice(direct ? g->devices[i] : d0));
+        hipStream_t st = direct ? g->mstream[i] : g->stream;
+        for (int k = 0; k < 4; ++k) {
+            if (!dst[k]) continue;
             const unsigned char *src = static_cast<const unsigned char *>(g->part[k][i].ptr);
-            if (g->devices[i] != d0) {
-                if ((rc = g->staged[k][i].ensure(d0, (size_t)rows[i] * row_bytes)) != RT_OK) return rc;
-                GHIP(hipMemcpyPeerAsync(g->staged[k][i].ptr, d0, g->part[k][i].ptr, g->devices[i], (size_t)rows[i] * row_bytes, g->stream));
+            if (!direct) {
+                GHIP(hipMemcpyPeerAsync(g->staged[k][i].ptr, d0, g->part[k][i].ptr, g->devices[i], (size_t)rows[i] * row_bytes[k], st));
                 src = static_cast<const unsigned char *>(g->staged[k][i].ptr);
             }
-            hipLaunchKernelGGL(k_place_rows, dim3((unsigned)rows[i]), dim3(256), 0, g->stream, src, frame, rows[i], (long long)row_bytes, band, n, i);
+            hipLaunchKernelGGL(k_place_rows, dim3((unsigned)rows[i]), dim3(256), 0, st, src, frame[k], rows[i], (long long)row_bytes[k], band, n, (int)i);
         }
         GHIP(hipGetLastError());
-        if (!out->on_device) GHIP(hipMemcpyAsync(dst[k], frame, (size_t)cam->resy * row_bytes, hipMemcpyDeviceToHost, g->stream));
+        GHIP(hipStreamSynchronize(st));
+        return (int)RT_OK;
+    });
+    if (rc != RT_OK) return rc;
+    if (!out->on_device) {
+        GHIP(hipSetDevice(d0));
+        for (int k = 0; k < 4; ++k)
+            if (dst[k]) GHIP(hipMemcpyAsync(dst[k], frame[k], (size_t)cam->resy * row_bytes[k], hipMemcpyDeviceToHost, g->stream));
+        GHIP(hipStreamSynchronize(g->stream));
     }
-    GHIP(hipStreamSynchronize(g->stream));
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         for (int i = 0; i < n; ++i) {
@@ -221,9 +263,12 @@ extern "C" int rt_group_render(rt_group *g, const rt_camera *cam, const rt_rende
             stats->shadow_rays += ms[i].shadow_rays;
             for (int q = 0; q < 6; ++q) { stats->rays_per_generation[q] += ms[i].rays_per_generation[q]; stats->hits_per_generation[q] += ms[i].hits_per_generation[q]; }
             if (ms[i].gpu_ms > stats->gpu_ms) stats->gpu_ms = ms[i].gpu_ms;       // the members run side by side
+            // (with RT_FLAG_TIMING: kernel times and launches summed over the members, which run side by side -- their sum is
+            // device time, not a share of gpu_ms)
             stats->closest_ms += ms[i].closest_ms; stats->shadow_ms += ms[i].shadow_ms; stats->pair_ms += ms[i].pair_ms;
+            stats->primary_ms += ms[i].primary_ms; stats->other_ms += ms[i].other_ms;
             stats->closest_launches += ms[i].closest_launches; stats->shadow_launches += ms[i].shadow_launches;
-            stats->pair_launches += ms[i].pair_launches;
+            stats->pair_launches += ms[i].pair_launches; stats->primary_launches += ms[i].primary_launches;
             stats->batches += ms[i].batches;
             stats->queue_overflow |= ms[i].queue_overflow;
         }

@@ -9,14 +9,18 @@ import raytracer_amd as rt
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("members,band", [(1, 16), (3, 16), (4, 7), (8, 1)])
-def test_group_frame_equals_single_context_and_oracle(oracle_frame, members, band):
+@pytest.mark.parametrize("members,band,staged", [(1, 16, 0), (3, 16, 0), (4, 7, 0), (8, 1, 0), (3, 5, 1)])
+def test_group_frame_equals_single_context_and_oracle(oracle_frame, members, band, staged):
+    """Every member writes its rows straight into the frame on the first device; with the option `staged` the parts go
+    through a peer copy to the first device and are placed there, the path of devices that cannot reach each other."""
     s = rt.Scene.load("teapot-3")
     cam = s.camera(150, 133)                    # neither a multiple of the band height nor of 4 bytes per row
     o = oracle_frame("teapot-3", res=(150, 133))
     g = rt.Group([0] * members)
+    g.set_option("staged", staged)
     g.upload(s)
-    fr = g.render(cam, band_rows=band, flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    fr = g.render(cam, band_rows=band, flags=rt.FLAG_KEEP_ZERO_WEIGHT | rt.FLAG_TIMING)
+    assert fr["stats"]["primary_launches"] >= members and fr["stats"]["primary_ms"] > 0
     assert np.array_equal(fr["rgb_u8"], o["rgb_u8"])
     assert np.array_equal(fr["hit_id"], o["hit_id"])
     assert np.abs(fr["rgb_f64"] - o["rgb_f64"]).max() <= 1e-9

@@ -13,24 +13,24 @@ names = ["start", "map", "filled", "rec", "queried", "geom", "accum", "reserved"
 for _ in range(2):
     g.render_device(cam, rgb_u8_ptr=u8.data_ptr(), num_samples=4)
 for nth in [int(a) for a in sys.argv[1:]] or [40, 200]:
-    for sel, label in ((0, "primary"), (1, "closest gen 1"), (8, "shadow gen 0"), (9, "shadow gen 1")):
+    for sel, label in ((0, "primary"), (8, "shadow gen 0"), (9, "shadow gen 1")):
         lib.rt_debug_stamp_select(sel + 256 * nth)
         buf = (C.c_ulonglong * (W * S))()
         lib.rt_debug_stamps(buf, W * S)          # clears
         g.render_device(cam, rgb_u8_ptr=u8.data_ptr(), num_samples=4)
         lib.rt_debug_stamps(buf, W * S)
         a = np.frombuffer(buf, dtype=np.uint64).reshape(W, S).astype(np.int64)
-        ok = (a[:, 3] > 0) & (a[:, 8] > 0)
+        ok = (a[:, 10] > 0) & (a[:, 8] > 0)
         if not ok.any():
             print(label, "nth", nth, ": no wave got that far"); continue
         w = a[ok]
         seg = []
-        last = 3
-        for k in range(4, 9):
+        last = 10
+        for k in range(3, 9):
             have = w[:, k] > 0
             if have.all():
-                d = (w[:, k] - w[:, last]) / 100.0
+                d = (w[:, k] - w[:, last]) / 2400.0
                 seg.append("%s %.2f (p90 %.2f)" % (names[k], np.median(d), np.percentile(d, 90)))
                 last = k
-        tot = (w[:, 8] - w[:, 3]) / 100.0
-        print("%-14s chunk %4d of %5d waves: us per segment: %s | whole chunk median %.2f p90 %.2f" % (label, nth, ok.sum(), ", ".join(seg), np.median(tot), np.percentile(tot, 90)), flush=True)
+        tot = (w[:, 8] - w[:, 10]) / 2400.0
+        print("%-14s chunk %4d of %5d waves: us (shader cycles / 2400) per segment: %s | whole chunk median %.2f p90 %.2f" % (label, nth, ok.sum(), ", ".join(seg), np.median(tot), np.percentile(tot, 90)), flush=True)
