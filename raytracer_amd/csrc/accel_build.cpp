@@ -569,22 +569,38 @@ void build(const rt_scene_desc &d, Accel &out, std::vector<rt_tri_rec> &octree_t
         for (const Item &it : *items)
             for (int k = 0; k < 3; ++k)
                 if (!(std::fabs(it.lo[k]) < 1e6) || !(std::fabs(it.hi[k]) < 1e6)) return;   // usable stays false
-    const int split_budget = opt.split_budget >= 0 ? opt.split_budget : kSplitBudgetPercent;
-    split_references(tri_items, d.tri, split_budget, opt.verbose);
-    Builder(tri_items, out.tri_bvh, leaf_max).run();
-    // spheres one to a leaf unless asked otherwise: a sphere's own box in the 4-wide node is a cheap single-precision test
-    // in front of its FP64 test (balls.nff at 4096 x 4096: 12.0 -> 11.6 ms; triangles are best at two, 69.7 vs 74.2 ms at one)
-    Builder(sph_items, out.sph_bvh, (opt.leaf_max >= 1 && opt.leaf_max <= 4) ? leaf_max : 1).run();
-    out.tri.reserve(tri_items.size());
-    for (const Item &it : tri_items) out.tri.push_back(octree_tri[it.src]);
-    out.sph.reserve(sph_items.size());
-    for (const Item &it : sph_items) {
-        out.sph.push_back(d.sph[it.src]);
-        out.sph_prim.push_back(d.sph_prim[it.src]);
-        out.sph_key.push_back(octree_sph_key[it.src]);
+    out.tri_on_device = opt.device_min > 0 && tri_items.size() >= 2 && (long long)tri_items.size() >= opt.device_min;
+    out.sph_on_device = opt.device_min > 0 && sph_items.size() >= 2 && (long long)sph_items.size() >= opt.device_min;
+    for (int k = 0; k < 3; ++k) { out.lo[k] = std::numeric_limits<double>::infinity(); out.hi[k] = -out.lo[k]; }
+    for (const std::vector<Item> *items : {&tri_items, &sph_items})
+        for (const Item &it : *items)
+            for (int k = 0; k < 3; ++k) { out.lo[k] = std::min(out.lo[k], it.lo[k]); out.hi[k] = std::max(out.hi[k], it.hi[k]); }
+    if (out.tri_on_device) {
+        out.tri_src.reserve(tri_items.size());
+        for (const Item &it : tri_items) out.tri_src.push_back(it.src);
+    } else {
+        const int split_budget = opt.split_budget >= 0 ? opt.split_budget : kSplitBudgetPercent;
+        split_references(tri_items, d.tri, split_budget, opt.verbose);
+        Builder(tri_items, out.tri_bvh, leaf_max).run();
+        out.tri.reserve(tri_items.size());
+        for (const Item &it : tri_items) out.tri.push_back(octree_tri[it.src]);
+        collapse(out.tri_bvh, out.tri_bvh4);
     }
-    collapse(out.tri_bvh, out.tri_bvh4);
-    collapse(out.sph_bvh, out.sph_bvh4);
+    if (out.sph_on_device) {
+        out.sph_src.reserve(sph_items.size());
+        for (const Item &it : sph_items) out.sph_src.push_back(it.src);
+    } else {
+        // spheres one to a leaf unless asked otherwise: a sphere's own box in the 4-wide node is a cheap single-precision test
+        // in front of its FP64 test (balls.nff at 4096 x 4096: 12.0 -> 11.6 ms; triangles are best at two, 69.7 vs 74.2 ms at one)
+        Builder(sph_items, out.sph_bvh, (opt.leaf_max >= 1 && opt.leaf_max <= 4) ? leaf_max : 1).run();
+        out.sph.reserve(sph_items.size());
+        for (const Item &it : sph_items) {
+            out.sph.push_back(d.sph[it.src]);
+            out.sph_prim.push_back(d.sph_prim[it.src]);
+            out.sph_key.push_back(octree_sph_key[it.src]);
+        }
+        collapse(out.sph_bvh, out.sph_bvh4);
+    }
     // a walk needs max_stack + 1 entries of its LDS stack
     out.usable = out.tri_bvh4.max_stack + 1 <= 64 && out.sph_bvh4.max_stack + 1 <= 64 &&
                  out.tri.size() < (1u << 28) && out.sph.size() < (1u << 28);

@@ -56,6 +56,11 @@ struct Accel {
     std::vector<uint32_t> sph_prim;     // primitive id | RT_SPH_TRANSPARENT
     std::vector<int32_t> sph_key;       // tie-break key
     bool usable = false;                // false: keep to the octree walk
+    // A hierarchy left to the device builder (lbvh_device.hpp; Options::device_min): its items as slots of the source
+    // record arrays, in primitive order, and the box of all of them; the 2- and 4-wide trees and the leaf arrays above stay empty.
+    bool tri_on_device = false, sph_on_device = false;
+    std::vector<int32_t> tri_src, sph_src;
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // box of every item of either kind (valid when anything is left to the device)
 };
 
 // Experiment knobs of the builder; the defaults are what the product uses.
@@ -63,6 +68,7 @@ struct Options {
     int leaf_max = 0;        // primitives per leaf, 1..4; 0 = default (2)
     int split_budget = -1;   // growth in percent allowed to reference splitting; < 0 = default (100), 0 = off
     bool verbose = false;    // splitter statistics on stderr
+    long long device_min = 0;   // > 0: a hierarchy over at least this many primitives is left to the device builder
 };
 
 // Also fills the per-slot helper fields of `octree_tri` (copy of desc.tri): key and the

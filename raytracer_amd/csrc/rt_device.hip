@@ -30,6 +30,7 @@
 #include "render_kernels.hpp"
 #include "lightcam_device.hpp"
 #include "viewgrid.hpp"
+#include "lbvh_device.hpp"
 #include <hipcub/hipcub.hpp>
 
 // ------------------------------------------------------------------ errors
@@ -93,6 +94,8 @@ struct DebugOptions {
     int units = 1;                  // 0: the primary pass never shares its chunks out on the device (every block keeps to a fixed share)
     int overlap = -1;               // 1: shadow passes on the second stream beside the next closest-hit pass, 0: one stream, -1: by batch size
     int pair = -1;                  // 1: shadow pass g and closest-hit pass g+1 in one launch, 0: a launch each, -1: default (paired)
+    int device_build_stack = BVH_STACK - 1;   // a device-built hierarchy whose walk could need more pending entries is built again on the host
+    long long device_build_min = 50000;   // hierarchies over at least this many primitives are built on the device (0: never); read at the next upload
     int grid = 1;                   // 0: no grids, every query walks the hierarchies; 1: lights' and eye's grids (viewgrid.hpp); 2: lights only; 3: eye only
     int grid_kernels = 1;           // 0: the passes that read the grids run in the general kernels (1024-thread blocks)
     int grid_res = 0;               // bins per edge of a face of a light's cube map (0: default)
@@ -169,6 +172,7 @@ struct rt_ctx {
     size_t cg_bins_cap = 0, cg_entries_words = 0;
     rt_camera cg_cam{};
     bool cg_valid = false;
+    rt_camera last_cam{}; bool last_cam_valid = false;        // the camera of the context's last frame of this scene
     int32_t cg_tiles_x = 0;
     void *grid_ws = nullptr; size_t grid_ws_bytes = 0;        // work space of the grid builder (grow-only)
     int cu_count = 256;
@@ -196,6 +200,7 @@ static int free_scene(rt_ctx *ctx)
     (void)hipFree(ctx->lg_entries); ctx->lg_entries = nullptr;
     ctx->grid_tri_index = nullptr;      // (one of scene_allocs)
     ctx->cg_valid = false;
+    ctx->last_cam_valid = false;
     for (void *p : ctx->scene_allocs) (void)hipFree(p);
     ctx->scene_allocs.clear();
     ctx->has_scene = false;
@@ -451,6 +456,111 @@ static int validate_scene(const rt_scene_desc *s)
 
 static int build_light_grids(rt_ctx *ctx, DevScene &D, int n_sph_records);
 
+// ------------------------------------------------------------------ hierarchy build on the device (lbvh_device.hpp)
+template <typename T>
+static int scene_alloc(rt_ctx *ctx, size_t n, T **out)
+{
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, sizeof(T) * (n ? n : 1)));
+    ctx->scene_allocs.push_back(p);
+    *out = static_cast<T *>(p);
+    return RT_OK;
+}
+
+struct DeviceTree {
+    const accel::Bvh4Node *nodes = nullptr;
+    int32_t n_nodes = 0, max_stack = 0, levels = 0;
+};
+
+// Builds the 4-wide hierarchy over the n items `src` (slots of the resident record array `tri` or `sph`) and leaves the order
+// of the leaves (sorted position -> item) in *order_out (device memory inside the returned work buffer, which the caller frees
+// after gathering the leaf records).
+static int lbvh_build(rt_ctx *ctx, hipStream_t st, bool is_tri, const rt_tri_rec *tri, const rt_sph_rec *sph, const std::vector<int32_t> &src,
+                      int leaf_max, const lbvh::Bounds &sb, DeviceTree &out, void **work_out, const int32_t **src_out, const uint32_t **order_out)
+{
+    const int n = (int)src.size();
+    *work_out = nullptr;
+    size_t sort_bytes = 0;
+    {
+        hipcub::DoubleBuffer<unsigned long long> dk(nullptr, nullptr);
+        hipcub::DoubleBuffer<uint32_t> dv(nullptr, nullptr);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, dk, dv, n, 0, 63, st));
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t N = (size_t)n;
+    const size_t o_src = take(N * 4), o_box = take(N * sizeof(lbvh::Box6)), o_code0 = take(N * 8), o_code1 = take(N * 8), o_ord0 = take(N * 4),
+                 o_ord1 = take(N * 4), o_left = take(N * 4), o_right = take(N * 4), o_first = take(N * 4), o_last = take(N * 4), o_pin = take(N * 4),
+                 o_pleaf = take(N * 4), o_ibox = take(N * sizeof(lbvh::Box6)), o_arr = take(N * 4), o_q0 = take(N * 4), o_q1 = take(N * 4),
+                 o_need = take(N * 4), o_ctr = take(64), o_sort = take(sort_bytes);
+    unsigned char *ws = nullptr;
+    HIP_TRY(hipMalloc((void **)&ws, off));
+    *work_out = ws;
+    int32_t *d_src = reinterpret_cast<int32_t *>(ws + o_src);
+    lbvh::Box6 *boxes = reinterpret_cast<lbvh::Box6 *>(ws + o_box), *iboxes = reinterpret_cast<lbvh::Box6 *>(ws + o_ibox);
+    unsigned long long *codes[2] = {reinterpret_cast<unsigned long long *>(ws + o_code0), reinterpret_cast<unsigned long long *>(ws + o_code1)};
+    uint32_t *ord[2] = {reinterpret_cast<uint32_t *>(ws + o_ord0), reinterpret_cast<uint32_t *>(ws + o_ord1)};
+    int32_t *left = reinterpret_cast<int32_t *>(ws + o_left), *right = reinterpret_cast<int32_t *>(ws + o_right),
+            *first = reinterpret_cast<int32_t *>(ws + o_first), *last = reinterpret_cast<int32_t *>(ws + o_last),
+            *pin = reinterpret_cast<int32_t *>(ws + o_pin), *pleaf = reinterpret_cast<int32_t *>(ws + o_pleaf);
+    uint32_t *arrived = reinterpret_cast<uint32_t *>(ws + o_arr);
+    int32_t *queue[2] = {reinterpret_cast<int32_t *>(ws + o_q0), reinterpret_cast<int32_t *>(ws + o_q1)};
+    int32_t *need = reinterpret_cast<int32_t *>(ws + o_need), *ctr = reinterpret_cast<int32_t *>(ws + o_ctr);
+    HIP_TRY(hipMemcpyAsync(d_src, src.data(), N * 4, hipMemcpyHostToDevice, st));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (is_tri) hipLaunchKernelGGL((lbvh::k_item_boxes<true>), dim3(nb), dim3(256), 0, st, tri, sph, d_src, n, sb, boxes, codes[0], ord[0]);
+    else hipLaunchKernelGGL((lbvh::k_item_boxes<false>), dim3(nb), dim3(256), 0, st, tri, sph, d_src, n, sb, boxes, codes[0], ord[0]);
+    hipcub::DoubleBuffer<unsigned long long> dk(codes[0], codes[1]);
+    hipcub::DoubleBuffer<uint32_t> dv(ord[0], ord[1]);
+    size_t sbytes = sort_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ws + o_sort, sbytes, dk, dv, n, 0, 63, st));
+    const unsigned long long *sorted_codes = dk.Current();
+    const uint32_t *order = dv.Current();
+    hipLaunchKernelGGL(lbvh::k_radix_tree, dim3(nb), dim3(256), 0, st, sorted_codes, n, left, right, first, last, pin, pleaf);
+    HIP_TRY(hipMemsetAsync(arrived, 0, N * 4, st));
+    hipLaunchKernelGGL(lbvh::k_fit_boxes, dim3(nb), dim3(256), 0, st, boxes, order, n, left, right, pin, pleaf, iboxes, arrived);
+    HIP_TRY(hipGetLastError());
+    // the fold, level by level from the root (binary inner node 0)
+    accel::Bvh4Node *nodes = nullptr;
+    int rc = scene_alloc(ctx, N, &nodes);            // a 4-wide node stands for at least one binary inner node: at most n - 1 of them
+    if (rc != RT_OK) return rc;
+    const int32_t zero = 0;
+    HIP_TRY(hipMemcpyAsync(queue[0], &zero, 4, hipMemcpyHostToDevice, st));
+    std::vector<std::pair<int32_t, int32_t>> levels;      // (first node, nodes)
+    int32_t base = 0, count = 1;
+    int cur = 0;
+    while (count > 0) {
+        if ((size_t)base + (size_t)count > N) return fail(RT_ERR_DEVICE, "device hierarchy build: more 4-wide nodes than binary ones");
+        HIP_TRY(hipMemsetAsync(ctr, 0, 8, st));
+        lbvh::FoldLevel L{};
+        L.queue = queue[cur]; L.count = count; L.base = base;
+        L.next_queue = queue[cur ^ 1]; L.next_count = ctr; L.next_cap = n; L.overflow = ctr + 1;
+        hipLaunchKernelGGL(lbvh::k_fold_level, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, L, left, right, first, last, iboxes, boxes, order,
+                           leaf_max, nodes);
+        int32_t h[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(h, ctr, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h[1]) return fail(RT_ERR_DEVICE, "device hierarchy build: level queue overflow");
+        levels.emplace_back(base, count);
+        base += count;
+        count = h[0];
+        cur ^= 1;
+        if (levels.size() > 200) return fail(RT_ERR_DEVICE, "device hierarchy build: the fold does not end");
+    }
+    for (size_t l = levels.size(); l-- > 0;)
+        hipLaunchKernelGGL(lbvh::k_stack_need, dim3((unsigned)((levels[l].second + 255) / 256)), dim3(256), 0, st, nodes, levels[l].first, levels[l].second, need);
+    int32_t need0 = 0;
+    HIP_TRY(hipMemcpyAsync(&need0, need, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    out.nodes = nodes;
+    out.n_nodes = base;
+    out.max_stack = need0;
+    out.levels = (int32_t)levels.size();
+    *src_out = d_src;
+    *order_out = order;
+    return RT_OK;
+}
+
 extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
 {
     if (!ctx || !s) return fail(RT_ERR_INVALID, "rt_upload_scene: null argument");
@@ -468,26 +578,108 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     aopt.leaf_max = ctx->dbg.leaf_max;
     aopt.split_budget = ctx->dbg.split_budget;
     aopt.verbose = ctx->dbg.verbose;
+    aopt.device_min = ctx->dbg.device_build_min;
+    const auto t_build = std::chrono::steady_clock::now();
     accel::build(*s, acc, octree_tri, octree_sph_key, aopt);
     if ((rc = upload(ctx, octree_tri.data(), octree_tri.size(), &D.tri)) != RT_OK) return rc;
-    if ((rc = upload(ctx, acc.tri_bvh4.nodes.data(), acc.tri_bvh4.nodes.size(), &D.tri_nodes)) != RT_OK) return rc;
-    if ((rc = upload(ctx, acc.sph_bvh4.nodes.data(), acc.sph_bvh4.nodes.size(), &D.sph_nodes)) != RT_OK) return rc;
-    if ((rc = upload(ctx, acc.tri.data(), acc.tri.size(), &D.btri)) != RT_OK) return rc;
-    if ((rc = upload(ctx, acc.sph.data(), acc.sph.size(), &D.bsph)) != RT_OK) return rc;
-    if ((rc = upload(ctx, acc.sph_prim.data(), acc.sph_prim.size(), &D.bsph_prim)) != RT_OK) return rc;
-    if ((rc = upload(ctx, acc.sph_key.data(), acc.sph_key.size(), &D.bsph_key)) != RT_OK) return rc;
-    D.n_tri_nodes = (int32_t)acc.tri_bvh4.nodes.size();
-    D.n_sph_nodes = (int32_t)acc.sph_bvh4.nodes.size();
-    {
-        const double bb = acc.tri_bvh4.max_abs_coord > acc.sph_bvh4.max_abs_coord ? acc.tri_bvh4.max_abs_coord
-                                                                                   : acc.sph_bvh4.max_abs_coord;
-        D.bvh_bound = (float)(bb * 1.000001 + 1e-30);
-    }
-    ctx->accel_usable = acc.usable;
-    ctx->n_btri = (long long)acc.tri.size();
-    ctx->accel_stack = acc.tri_bvh4.max_stack > acc.sph_bvh4.max_stack ? acc.tri_bvh4.max_stack : acc.sph_bvh4.max_stack;
     if ((rc = upload(ctx, s->sph, (size_t)s->n_sph_slots, &D.sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->sph_prim, (size_t)s->n_sph_slots, &D.sph_prim)) != RT_OK) return rc;
+    long long n_btri = (long long)acc.tri.size(), n_bsph = (long long)acc.sph.size();
+    int stack_tri = acc.tri_bvh4.max_stack, stack_sph = acc.sph_bvh4.max_stack;
+    double max_abs = acc.tri_bvh4.max_abs_coord > acc.sph_bvh4.max_abs_coord ? acc.tri_bvh4.max_abs_coord : acc.sph_bvh4.max_abs_coord;
+    bool usable = acc.usable;
+    if (acc.tri_on_device || acc.sph_on_device) {
+        // Large hierarchies are built on the device (lbvh_device.hpp) from the record arrays that are resident by now.
+        lbvh::Bounds sb;
+        for (int k = 0; k < 3; ++k) {
+            sb.lo[k] = acc.lo[k];
+            sb.inv[k] = acc.hi[k] > acc.lo[k] ? 1.0 / (acc.hi[k] - acc.lo[k]) : 0.0;
+            // (the boxes get a relative slack of 1e-7 and are rounded outward to single precision)
+            max_abs = std::max({max_abs, std::fabs(acc.lo[k]) * 1.000001 + 1e-6, std::fabs(acc.hi[k]) * 1.000001 + 1e-6});
+        }
+        const int leaf_tri = (aopt.leaf_max >= 1 && aopt.leaf_max <= 4) ? aopt.leaf_max : 2;
+        const int leaf_sph = (aopt.leaf_max >= 1 && aopt.leaf_max <= 4) ? aopt.leaf_max : 1;
+        if (acc.tri_on_device) {
+            DeviceTree t;
+            void *work = nullptr;
+            const int32_t *d_src = nullptr;
+            const uint32_t *d_order = nullptr;
+            rc = lbvh_build(ctx, ctx->stream, true, D.tri, D.sph, acc.tri_src, leaf_tri, sb, t, &work, &d_src, &d_order);
+            rt_tri_rec *leaves = nullptr;
+            if (rc == RT_OK) rc = scene_alloc(ctx, acc.tri_src.size(), &leaves);
+            if (rc == RT_OK) {
+                const long long pieces = (long long)acc.tri_src.size() * 6;
+                hipLaunchKernelGGL(lbvh::k_gather_tri, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, ctx->stream, D.tri, d_src, d_order,
+                                   (int)acc.tri_src.size(), leaves);
+                if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(RT_ERR_DEVICE, "device hierarchy build: gathering the leaf records failed");
+            }
+            (void)hipFree(work);
+            if (rc != RT_OK) return rc;
+            D.tri_nodes = t.nodes; D.n_tri_nodes = t.n_nodes; D.btri = leaves;
+            n_btri = (long long)acc.tri_src.size();
+            stack_tri = t.max_stack;
+            if (ctx->dbg.verbose) fprintf(stderr, "[rt] triangle hierarchy on the device: %zu triangles, %d nodes in %d levels, stack %d\n", acc.tri_src.size(), t.n_nodes, t.levels, t.max_stack);
+        }
+        if (acc.sph_on_device) {
+            DeviceTree t;
+            void *work = nullptr;
+            const int32_t *d_src = nullptr, *d_keys = nullptr;
+            const uint32_t *d_order = nullptr;
+            rc = lbvh_build(ctx, ctx->stream, false, D.tri, D.sph, acc.sph_src, leaf_sph, sb, t, &work, &d_src, &d_order);
+            rt_sph_rec *leaves = nullptr;
+            uint32_t *leaf_prim = nullptr;
+            int32_t *leaf_key = nullptr;
+            const size_t ns = acc.sph_src.size();
+            if (rc == RT_OK) rc = upload(ctx, octree_sph_key.data(), octree_sph_key.size(), &d_keys);
+            if (rc == RT_OK) rc = scene_alloc(ctx, ns, &leaves);
+            if (rc == RT_OK) rc = scene_alloc(ctx, ns, &leaf_prim);
+            if (rc == RT_OK) rc = scene_alloc(ctx, ns, &leaf_key);
+            if (rc == RT_OK) {
+                hipLaunchKernelGGL(lbvh::k_gather_sph, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, D.sph, D.sph_prim, d_keys, d_src,
+                                   d_order, (int)ns, leaves, leaf_prim, leaf_key);
+                if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(RT_ERR_DEVICE, "device hierarchy build: gathering the leaf records failed");
+            }
+            (void)hipFree(work);
+            if (rc != RT_OK) return rc;
+            D.sph_nodes = t.nodes; D.n_sph_nodes = t.n_nodes; D.bsph = leaves; D.bsph_prim = leaf_prim; D.bsph_key = leaf_key;
+            n_bsph = (long long)ns;
+            stack_sph = t.max_stack;
+            if (ctx->dbg.verbose) fprintf(stderr, "[rt] sphere hierarchy on the device: %zu spheres, %d nodes in %d levels, stack %d\n", ns, t.n_nodes, t.levels, t.max_stack);
+        }
+        const int cap = ctx->dbg.device_build_stack < BVH_STACK - 1 ? ctx->dbg.device_build_stack : BVH_STACK - 1;
+        if ((acc.tri_on_device && stack_tri > cap) || (acc.sph_on_device && stack_sph > cap)) {
+            // A curve-ordered tree over badly distributed primitives can be deeper than the walks' stacks: the host builder's
+            // is balanced by construction.  (What the device built stays allocated until the next scene replaces it.)
+            if (ctx->dbg.verbose) fprintf(stderr, "[rt] device-built hierarchies too deep (stack %d / %d): building on the host\n", stack_tri, stack_sph);
+            aopt.device_min = 0;
+            accel::build(*s, acc, octree_tri, octree_sph_key, aopt);
+            n_btri = (long long)acc.tri.size(); n_bsph = (long long)acc.sph.size();
+            stack_tri = acc.tri_bvh4.max_stack; stack_sph = acc.sph_bvh4.max_stack;
+            max_abs = acc.tri_bvh4.max_abs_coord > acc.sph_bvh4.max_abs_coord ? acc.tri_bvh4.max_abs_coord : acc.sph_bvh4.max_abs_coord;
+            usable = acc.usable;
+        }
+    }
+    if (!acc.tri_on_device) {
+        if ((rc = upload(ctx, acc.tri_bvh4.nodes.data(), acc.tri_bvh4.nodes.size(), &D.tri_nodes)) != RT_OK) return rc;
+        if ((rc = upload(ctx, acc.tri.data(), acc.tri.size(), &D.btri)) != RT_OK) return rc;
+        D.n_tri_nodes = (int32_t)acc.tri_bvh4.nodes.size();
+    }
+    if (!acc.sph_on_device) {
+        if ((rc = upload(ctx, acc.sph_bvh4.nodes.data(), acc.sph_bvh4.nodes.size(), &D.sph_nodes)) != RT_OK) return rc;
+        if ((rc = upload(ctx, acc.sph.data(), acc.sph.size(), &D.bsph)) != RT_OK) return rc;
+        if ((rc = upload(ctx, acc.sph_prim.data(), acc.sph_prim.size(), &D.bsph_prim)) != RT_OK) return rc;
+        if ((rc = upload(ctx, acc.sph_key.data(), acc.sph_key.size(), &D.bsph_key)) != RT_OK) return rc;
+        D.n_sph_nodes = (int32_t)acc.sph_bvh4.nodes.size();
+    }
+    if (acc.tri_on_device || acc.sph_on_device)
+        usable = acc.usable && stack_tri + 1 <= 64 && stack_sph + 1 <= 64 && n_btri < (1ll << 28) && n_bsph < (1ll << 28);
+    D.bvh_bound = (float)(max_abs * 1.000001 + 1e-30);
+    ctx->accel_usable = usable;
+    ctx->n_btri = n_btri;
+    ctx->accel_stack = stack_tri > stack_sph ? stack_tri : stack_sph;
+    if (ctx->dbg.verbose)
+        fprintf(stderr, "[rt] hierarchies ready %.1f ms after the upload began their part (%lld triangle and %lld sphere leaf records)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count(), n_btri, n_bsph);
     if ((rc = upload(ctx, s->prim_flags, (size_t)s->n_prims, &D.prim_flags)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->prim_material, (size_t)s->n_prims, &D.prim_material)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->prim_normals, (size_t)s->n_prims * 12, &D.prim_normals)) != RT_OK) return rc;
@@ -562,11 +754,13 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
             const int32_t p = acc.tri[k].prim;
             if (!seen[(size_t)p]) { seen[(size_t)p] = 1; first_record.push_back((int32_t)k); }
         }
+        if (acc.tri_on_device)       // (built on the device: a leaf record per primitive, no pieces)
+            for (size_t k = 0; k < acc.tri_src.size(); ++k) first_record.push_back((int32_t)k);
         const int32_t *d_index = nullptr;
         if ((rc = upload(ctx, first_record.data(), first_record.size(), &d_index)) != RT_OK) return rc;
         ctx->grid_tri_index = const_cast<int32_t *>(d_index);
         ctx->n_grid_tri = (int32_t)first_record.size();
-        ctx->n_grid_sph = (int32_t)acc.sph.size();
+        ctx->n_grid_sph = (int32_t)(acc.sph_on_device ? acc.sph_src.size() : acc.sph.size());
         if ((rc = build_light_grids(ctx, D, ctx->n_grid_sph)) != RT_OK) return rc;
     }
     ctx->S = D;
@@ -1499,12 +1693,17 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const size_t lds_closest = lds_bvh;
     const size_t lds_shadow = lds_bvh;
     const bool use_lightcam = P.S.lc_table != nullptr && !bvh_shadow_ok && P.S.n_lights > 0;
-    // the eye's grid (viewgrid.hpp): pinhole frames large enough to pay for it (it is kept while the camera stays)
+    // The eye's grid (viewgrid.hpp), for pinhole frames.  Making it costs about a millisecond, more than a small frame takes,
+    // and it is kept while the camera stays: a frame of at least 4 M samples gets it at once, a smaller one when its camera
+    // is the one of the frame before (a camera at rest; one that moves from frame to frame walks the hierarchies).
     P.cg_bins = nullptr; P.cg_entries = nullptr; P.cg_tiles_x = (cam->resx + 7) / 8;
     {
         const long long cg_min = ctx->dbg.grid_min_samples >= 0 ? ctx->dbg.grid_min_samples : (1ll << 22);
+        const bool same_camera = ctx->last_cam_valid && std::memcmp(&ctx->last_cam, cam, sizeof(rt_camera)) == 0;
+        ctx->last_cam = *cam;
+        ctx->last_cam_valid = true;
         if (bvh_closest_ok && !noalloc && !use_fused && local_rows > 0 && (ctx->dbg.grid == 1 || ctx->dbg.grid == 3) && !(o->aperture > 0) &&
-            (long long)n_pixels * spp >= cg_min) {
+            ((long long)n_pixels * spp >= cg_min || (same_camera && ctx->dbg.grid_min_samples < 0))) {
             const int grc = provide_camera_grid(ctx, cam, ctx->n_grid_sph);
             if (grc == RT_OK) { P.cg_bins = ctx->cg_bins; P.cg_entries = ctx->cg_entries; P.cg_tiles_x = ctx->cg_tiles_x; }
             else if (grc != RT_ERR_CAPACITY && grc != RT_ERR_UNSUPPORTED) return grc;
@@ -2172,6 +2371,8 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "grid") { ctx->dbg.grid = (int)value; ctx->cg_valid = false; }          // (lights' grids: read at the next upload)
     else if (n == "grid_res") ctx->dbg.grid_res = (int)value;
     else if (n == "grid_kernels") ctx->dbg.grid_kernels = (int)value;
+    else if (n == "device_build_min") ctx->dbg.device_build_min = value;
+    else if (n == "device_build_stack") ctx->dbg.device_build_stack = (int)value;
     else if (n == "grid_min_samples") ctx->dbg.grid_min_samples = value;
     else if (n == "lightcam_pool") ctx->dbg.lightcam_pool = value < 128 ? 128 : (value > LC_POOL ? LC_POOL : (int)value);
     else if (n == "queue_growth") ctx->growth = value < 1 ? 1 : (value > 32 ? 32 : (int)value);

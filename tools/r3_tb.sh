@@ -15,3 +15,5 @@ j=json.loads(open(p).read().strip().splitlines()[-1])
 print("%-14s %9.1f Mrays/s  %9.3f ms/step  pinned frame: %s" % (w, j["value"], j["ms_per_step"], j["frame_matches_pinned"]))
 PY
 done
+[ -n "$R3_BUILD_EXP" ] && timeout -k 10 400 python -u tools/exp_build.py 2>&1 | grep -v amdgpu.ids
+exit 0
