@@ -172,6 +172,7 @@ struct rt_ctx {
     size_t cg_bins_cap = 0, cg_entries_words = 0;
     rt_camera cg_cam{};
     bool cg_valid = false;
+    bool cg_refused = false;              // the grid of camera cg_cam would have lists too long to be worth reading
     rt_camera last_cam{}; bool last_cam_valid = false;        // the camera of the context's last frame of this scene
     int32_t cg_tiles_x = 0;
     void *grid_ws = nullptr; size_t grid_ws_bytes = 0;        // work space of the grid builder (grow-only)
@@ -200,6 +201,7 @@ static int free_scene(rt_ctx *ctx)
     (void)hipFree(ctx->lg_entries); ctx->lg_entries = nullptr;
     ctx->grid_tri_index = nullptr;      // (one of scene_allocs)
     ctx->cg_valid = false;
+    ctx->cg_refused = false;
     ctx->last_cam_valid = false;
     for (void *p : ctx->scene_allocs) (void)hipFree(p);
     ctx->scene_allocs.clear();
@@ -1178,14 +1180,19 @@ static int provide_lightcams(rt_ctx *ctx, uint32_t lc_flags, bool cull, bool may
 // drained once in between, when the number of entries is read.  *bins_out / *entries_out are grown when too small.
 #define VG_LARGE_CAP (1u << 18)
 static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> &builds, size_t total_bins, vg::Bin **bins_out,
-                            size_t *bins_cap, vg::Entry **entries_out, size_t *entries_words, size_t *n_entries_out)
+                            size_t *bins_cap, vg::Entry **entries_out, size_t *entries_words, size_t *n_entries_out, size_t max_per_bin)
 {
     const size_t nb = builds.size();
+    // Bin counts and list positions are 32-bit: an item that is not listed as large enters at most VG_LARGE_BINS bins, the
+    // large ones are summed in 64 bits while they are counted, and a build that could pass 2^31 entries is not made.
+    unsigned long long small_bound = 0;
+    for (const vg::Build &B : builds) small_bound += (unsigned long long)VG_LARGE_BINS * (unsigned long long)(B.n_tri + B.n_sph) * (unsigned long long)B.n_faces;
+    if (small_bound >= (1ull << 31)) return RT_ERR_UNSUPPORTED;
     size_t scan_bytes = 0;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)(total_bins + 1), st));
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_bins = take((total_bins + 1) * 4), o_begin = take((total_bins + 1) * 4), o_large = take(nb * VG_LARGE_CAP * 4), o_ctr = take((nb + 1) * 4), o_scan = take(scan_bytes);
+    const size_t o_bins = take((total_bins + 1) * 4), o_begin = take((total_bins + 1) * 4), o_large = take(nb * VG_LARGE_CAP * 4), o_ctr = take((nb + 1) * 4), o_total = take(8), o_scan = take(scan_bytes);
     int rc = ws_ensure(&ctx->grid_ws, &ctx->grid_ws_bytes, off);
     if (rc != RT_OK) return rc;
     unsigned char *ws = static_cast<unsigned char *>(ctx->grid_ws);
@@ -1199,6 +1206,7 @@ static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> 
     }
     HIP_TRY(hipMemsetAsync(bins, 0, (total_bins + 1) * 4, st));
     HIP_TRY(hipMemsetAsync(ctr, 0, (nb + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(ws + o_total, 0, 8, st));
     auto launch = [&](bool fill) {
         for (size_t b = 0; b < nb; ++b) {
             vg::Build &B = builds[b];
@@ -1207,6 +1215,7 @@ static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> 
             B.n_large = ctr + b;
             B.large_cap = VG_LARGE_CAP;
             B.overflow = ctr + nb;
+            B.large_total = reinterpret_cast<unsigned long long *>(ws + o_total);
             B.entries = fill ? *entries_out : nullptr;
             const long long threads = (long long)(B.n_tri + B.n_sph) * B.n_faces;
             if (threads <= 0) continue;
@@ -1225,10 +1234,17 @@ static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> 
     size_t sb = scan_bytes;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws + o_scan, sb, bins, begin, (int)(total_bins + 1), st));
     uint32_t total = 0, overflow = 0;
+    unsigned long long large_total = 0;
     HIP_TRY(hipMemcpyAsync(&total, begin + total_bins, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&overflow, ctr + nb, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&large_total, ws + o_total, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (overflow) return fail(RT_ERR_CAPACITY, "view grids: too many items that cover many bins");
+    if (small_bound + large_total >= (1ull << 31)) return RT_ERR_UNSUPPORTED;
+    // Lists this long are no shorter than what a walk of the hierarchy tests (a dense scene seen through few bins): measured
+    // on 320 000 triangles and 100 000 spheres, 18 entries per tile 0.99 against 1.13 ms, 50 per tile 4.64 against 4.71, 139 per
+    // tile 2.23 against 1.64.
+    if (max_per_bin && (size_t)total > max_per_bin * total_bins) return RT_ERR_UNSUPPORTED;
     if (*entries_words < (size_t)total + 4) {
         (void)hipFree(*entries_out); *entries_out = nullptr; *entries_words = 0;
         const size_t want = (size_t)total + (size_t)total / 4 + 1024;
@@ -1293,12 +1309,12 @@ static int build_light_grids(rt_ctx *ctx, DevScene &D, int n_sph_records)
     }
     size_t bins_cap = 0, entries_words = 0, n_entries = 0;
     int rc = build_view_grids(ctx, ctx->stream, builds, per_light * (size_t)D.n_lights, &ctx->lg_bins, &bins_cap, &ctx->lg_entries,
-                              &entries_words, &n_entries);
+                              &entries_words, &n_entries, ctx->dbg.grid_res > 0 ? 0 : 32);      // (a grid asked for by size is made whatever its lists)
     if (rc != RT_OK) {
         // (no grids: the hierarchies answer; not an error of the upload)
         (void)hipFree(ctx->lg_bins); ctx->lg_bins = nullptr;
         (void)hipFree(ctx->lg_entries); ctx->lg_entries = nullptr;
-        if (rc == RT_ERR_CAPACITY) return RT_OK;
+        if (rc == RT_ERR_CAPACITY || rc == RT_ERR_UNSUPPORTED) return RT_OK;
         return rc;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1316,7 +1332,9 @@ static int build_light_grids(rt_ctx *ctx, DevScene &D, int n_sph_records)
 static int provide_camera_grid(rt_ctx *ctx, const rt_camera *cam, int n_sph_records)
 {
     if (ctx->cg_valid && std::memcmp(&ctx->cg_cam, cam, sizeof(rt_camera)) == 0) return RT_OK;
+    if (ctx->cg_refused && std::memcmp(&ctx->cg_cam, cam, sizeof(rt_camera)) == 0) return RT_ERR_UNSUPPORTED;
     ctx->cg_valid = false;
+    ctx->cg_refused = false;
     const int tx = (cam->resx + 7) / 8, ty = (cam->resy + 7) / 8;
     std::vector<vg::Build> builds(1);
     vg::Build &B = builds[0];
@@ -1351,7 +1369,8 @@ static int provide_camera_grid(rt_ctx *ctx, const rt_camera *cam, int n_sph_reco
     size_t n_entries = 0;
     const auto t_begin = std::chrono::steady_clock::now();
     int rc = build_view_grids(ctx, ctx->stream, builds, (size_t)tx * ty, &ctx->cg_bins, &ctx->cg_bins_cap, &ctx->cg_entries,
-                              &ctx->cg_entries_words, &n_entries);
+                              &ctx->cg_entries_words, &n_entries, ctx->dbg.grid_min_samples >= 0 ? 0 : 48);
+    if (rc == RT_ERR_UNSUPPORTED) { ctx->cg_cam = *cam; ctx->cg_refused = true; }      // (not asked again while the camera stays)
     if (rc != RT_OK) return rc;
     ctx->cg_cam = *cam;
     ctx->cg_tiles_x = tx;
@@ -1617,8 +1636,17 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const bool want_local = !noalloc && !use_fused && local_rows > 0 && may_cull && ctx->accel_usable && batch_chunks >= n_chunks &&
                             (ctx->dbg.local == 1 || (ctx->dbg.local < 0 && n_chunks * 64 <= RT_LOCAL_MAX_SAMPLES));
     int block = want_local ? ctx->dbg.local_threads : (noalloc || use_fused || batch_chunks * 64 <= (1ll << 22)) ? 256 : RT_BLOCK;
+    // A hierarchy so deep that the stacks of 1024 threads do not fit a compute unit's LDS is walked in blocks of 256, as many to a
+    // compute unit as their stacks leave room for (three at 40 entries): fewer waves in flight, but the hierarchy and not the
+    // octree walk, which on a scene large enough to have such a hierarchy is hundreds of times slower.
+    const size_t stack_bytes_per_thread = (size_t)stack_entries * sizeof(int);
+    const bool deep = may_cull && ctx->accel_usable && !use_fused && stack_bytes_per_thread * 1024 + 8192 > ctx->lds_per_cu;
+    if (deep) block = 256;
     if (!use_fused && (ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024)) block = ctx->dbg.block_threads;
-    const int blocks_per_cu = 1024 / block, waves_per_block = block / 64;
+    int fit_per_cu = 1024 / block;
+    if (deep && block == 256)
+        while (fit_per_cu > 1 && (stack_bytes_per_thread * 256 + 4096) * (size_t)fit_per_cu > ctx->lds_per_cu) --fit_per_cu;
+    const int blocks_per_cu = fit_per_cu, waves_per_block = block / 64;
     // k_local: primary chunks per block (one run per resident wave slot) and the records a block's ray list can hold
     // (with two rays per hit, `growth` times the first generation, as in plan_queues); beside its counters the block keeps
     // a word per 64 records of the ray lists of generations 1..5 in LDS
@@ -2368,12 +2396,12 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "overlap") ctx->dbg.overlap = (int)value;
     else if (n == "pair") ctx->dbg.pair = (int)value;
     else if (n == "ring_poison") ctx->dbg.ring_poison = value != 0;
-    else if (n == "grid") { ctx->dbg.grid = (int)value; ctx->cg_valid = false; }          // (lights' grids: read at the next upload)
+    else if (n == "grid") { ctx->dbg.grid = (int)value; ctx->cg_valid = false; ctx->cg_refused = false; }          // (lights' grids: read at the next upload)
     else if (n == "grid_res") ctx->dbg.grid_res = (int)value;
     else if (n == "grid_kernels") ctx->dbg.grid_kernels = (int)value;
     else if (n == "device_build_min") ctx->dbg.device_build_min = value;
     else if (n == "device_build_stack") ctx->dbg.device_build_stack = (int)value;
-    else if (n == "grid_min_samples") ctx->dbg.grid_min_samples = value;
+    else if (n == "grid_min_samples") { ctx->dbg.grid_min_samples = value; ctx->cg_refused = false; }
     else if (n == "lightcam_pool") ctx->dbg.lightcam_pool = value < 128 ? 128 : (value > LC_POOL ? LC_POOL : (int)value);
     else if (n == "queue_growth") ctx->growth = value < 1 ? 1 : (value > 32 ? 32 : (int)value);
     else return fail(RT_ERR_INVALID, "rt_debug_set_option: unknown option '" + n + "'");

@@ -71,7 +71,8 @@ struct Build {
     uint32_t *large;               // (item * 8 + face) of the items left to the block-per-item kernel
     uint32_t *n_large;
     uint32_t large_cap;
-    uint32_t *overflow;            // raised when `large` is full (the grid is then not used)
+    uint32_t *overflow;
+    unsigned long long *large_total;   // entries of the large items, summed while they are counted            // raised when `large` is full (the grid is then not used)
 };
 
 // The projection of one item on one face: a convex polygon of at most four corners (n = 0: nothing of it in front),
@@ -190,21 +191,33 @@ __device__ inline Shape project_sphere(const Build &B, const Face &f, const rt_s
         return whole_face(f);
     }
     const double flat_depth = s.flat == s.flat ? s.flat : 0.0;
-    // The sphere reaches the plane depth = z_near, or the point lies inside it: no finite silhouette on this face.
-    if (!(cz - r * wl * (1.0 + 1e-6) > B.z_near)) { Shape a = whole_face(f); a.flat = flat_depth; return a; }
-    // Tangent lines through the point in the planes (u, w) and (v, w), in world lengths: with the centre at (a, z) and
-    // z > r the slopes t of the lines x = t z that touch the circle are (a z -+ r sqrt(a^2 + z^2 - r^2)) / (z^2 - r^2).
+    // The point lies inside the sphere (or as good as): every direction meets it.
+    if (!(s.flat > 0.0)) { Shape a = whole_face(f); a.flat = 0.0; return a; }
+    // Tangent lines through the point in the planes (u, w) and (v, w), in world lengths.  With the centre at (a, z), at the
+    // distance D from the point, and L^2 = D^2 - r^2 > 0, the directions (x, depth) of the two tangents are
+    // (a L + z r, z L - a r) and (a L - z r, z L + a r); the sphere's directions lie between them.  A tangent that points
+    // backward (depth <= 0: the sphere reaches through the plane depth = 0 on that side) leaves that side open; a sphere that
+    // does not reach the plane has both in front, and the slopes are (a z +- r L) / (z^2 - r^2).  L^2 <= 0 (the point is inside
+    // the sphere's shadow on that plane) leaves both sides open.
     const double ul = sqrt(dot3a(f.u, f.u[0], f.u[1], f.u[2])), vl = sqrt(dot3a(f.v, f.v[0], f.v[1], f.v[2]));
     const double z = cz / wl;
+    const double open_end = 1e300;
     double lo[2], hi[2];
     for (int k = 0; k < 2; ++k) {
         const double a = (k == 0 ? cx / ul : cy / vl), scale = (k == 0 ? ul : vl) / wl;
-        const double den = z * z - r * r;                   // > 0 here
-        const double root = r * sqrt((a * a + z * z) - r * r);
-        lo[k] = (a * z - root) / den * scale;
-        hi[k] = (a * z + root) / den * scale;
-        const double slack = 1e-9 * (fabs(lo[k]) + fabs(hi[k]));
-        lo[k] -= slack; hi[k] += slack;
+        const double l2 = (a * a + z * z) - r * r;
+        lo[k] = -open_end; hi[k] = open_end;
+        if (!(l2 > 1e-12 * (a * a + z * z))) continue;
+        const double L = sqrt(l2);
+        const double z_hi = z * L - a * r, z_lo = z * L + a * r, tiny = 1e-9 * (fabs(z) * L + fabs(a) * r);
+        if (z_hi > tiny) {
+            hi[k] = (a * L + z * r) / z_hi * scale;
+            hi[k] += 1e-9 * fabs(hi[k]);
+        }
+        if (z_lo > tiny) {
+            lo[k] = (a * L - z * r) / z_lo * scale;
+            lo[k] -= 1e-9 * fabs(lo[k]);
+        }
     }
     if (!(lo[0] == lo[0]) || !(hi[0] == hi[0]) || !(lo[1] == lo[1]) || !(hi[1] == hi[1])) { Shape a = whole_face(f); a.flat = flat_depth; return a; }
     s.flat = flat_depth;
@@ -329,13 +342,16 @@ __global__ __launch_bounds__(256) void k_grid_large(Build B)
         const uint32_t e = entry_of(B, item);
         const int w = s.bx1 - s.bx0 + 1;
         const long long nb = (long long)w * (s.by1 - s.by0 + 1);
+        unsigned long long mine = 0;
         for (long long k = threadIdx.x; k < nb; k += blockDim.x) {
             const int by = s.by0 + (int)(k / w), bx = s.bx0 + (int)(k - (long long)(by - s.by0) * w);
             if (!bin_touches(B, f, s, bx, by)) continue;
             const uint32_t bin = f.first_bin + (uint32_t)by * (uint32_t)f.nx + (uint32_t)bx;
             const uint32_t at = atomicAdd(&B.bins[bin], 1u);
             if (FILL) { Entry en; en.id = e; en.depth = bin_depth(B, f, s, bx, by); B.entries[at] = en; }
+            ++mine;
         }
+        if (!FILL && mine) atomicAdd(B.large_total, mine);
     }
 }
 
