@@ -593,9 +593,13 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     if (acc.tri_on_device || acc.sph_on_device) {
         // Large hierarchies are built on the device (lbvh_device.hpp) from the record arrays that are resident by now.
         lbvh::Bounds sb;
+        // (one scale for the three axes: the curve's cells are cubes, and a flat scene is not cut along its thin side as finely
+        // as along the others, which made the trees deeper)
+        double widest = 0.0;
+        for (int k = 0; k < 3; ++k) widest = std::max(widest, acc.hi[k] - acc.lo[k]);
         for (int k = 0; k < 3; ++k) {
             sb.lo[k] = acc.lo[k];
-            sb.inv[k] = acc.hi[k] > acc.lo[k] ? 1.0 / (acc.hi[k] - acc.lo[k]) : 0.0;
+            sb.inv[k] = widest > 0.0 ? 1.0 / widest : 0.0;
             // (the boxes get a relative slack of 1e-7 and are rounded outward to single precision)
             max_abs = std::max({max_abs, std::fabs(acc.lo[k]) * 1.000001 + 1e-6, std::fabs(acc.hi[k]) * 1.000001 + 1e-6});
         }
@@ -1636,42 +1640,51 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     const bool want_local = !noalloc && !use_fused && local_rows > 0 && may_cull && ctx->accel_usable && batch_chunks >= n_chunks &&
                             (ctx->dbg.local == 1 || (ctx->dbg.local < 0 && n_chunks * 64 <= RT_LOCAL_MAX_SAMPLES));
     int block = want_local ? ctx->dbg.local_threads : (noalloc || use_fused || batch_chunks * 64 <= (1ll << 22)) ? 256 : RT_BLOCK;
-    // A hierarchy so deep that the stacks of 1024 threads do not fit a compute unit's LDS is walked in blocks of 256, as many to a
-    // compute unit as their stacks leave room for (three at 40 entries): fewer waves in flight, but the hierarchy and not the
-    // octree walk, which on a scene large enough to have such a hierarchy is hundreds of times slower.
-    const size_t stack_bytes_per_thread = (size_t)stack_entries * sizeof(int);
-    const bool deep = may_cull && ctx->accel_usable && !use_fused && stack_bytes_per_thread * 1024 + 8192 > ctx->lds_per_cu;
-    if (deep) block = 256;
-    if (!use_fused && (ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024)) block = ctx->dbg.block_threads;
-    int fit_per_cu = 1024 / block;
-    if (deep && block == 256)
-        while (fit_per_cu > 1 && (stack_bytes_per_thread * 256 + 4096) * (size_t)fit_per_cu > ctx->lds_per_cu) --fit_per_cu;
-    const int blocks_per_cu = fit_per_cu, waves_per_block = block / 64;
     // k_local: primary chunks per block (one run per resident wave slot) and the records a block's ray list can hold
     // (with two rays per hit, `growth` times the first generation, as in plan_queues); beside its counters the block keeps
     // a word per 64 records of the ray lists of generations 1..5 in LDS
     long long local_cpb = 0, local_cap = 0, local_grid = 0;
     size_t local_lds = 0;
-    bool local_fits = want_local;
-    if (want_local) {
+    auto plan_local = [&](int per_cu) {
         // every compute unit gets a block as soon as there are `min_chunks` primary chunks for each (a frame of 4800 chunks
         // cut into runs of whole rounds of waves was 150 blocks of 32 chunks on a chip of 256 compute units)
-        const long long resident = (long long)ctx->cu_count * blocks_per_cu;
+        const long long resident = (long long)ctx->cu_count * per_cu;
         const long long min_chunks = ctx->dbg.local_min_chunks > 0 ? ctx->dbg.local_min_chunks : 4;
         local_grid = (n_chunks + min_chunks - 1) / min_chunks;
         if (local_grid > resident) local_grid = resident;
         local_cpb = (n_chunks + local_grid - 1) / local_grid;
         local_cap = local_cpb * 64 * (ctx->any_transparent ? (long long)ctx->growth : 1ll);
         local_lds = (size_t)(CNT_WORDS + 32 + 5 * (local_cap / 64)) * sizeof(uint32_t);
-        if (local_lds > 24 * 1024) local_fits = false;       // (deep queues after overflows: the launch-per-pass path takes over)
+    };
+    if (!use_fused && (ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024)) block = ctx->dbg.block_threads;
+    if (want_local) plan_local(1024 / block);
+    // A hierarchy so deep that the stacks of a full compute unit (1024 threads) do not fit its LDS beside the tables (and the
+    // lists of k_local) is walked in blocks of 256, as many to a compute unit as their stacks leave room for (three at 40
+    // entries): fewer waves in flight, but the hierarchy and not the octree walk, which on a scene large enough to have such
+    // a hierarchy is hundreds of times slower.
+    const size_t stack_bytes_per_thread = (size_t)stack_entries * sizeof(int);
+    const size_t lds_beside_stacks = 8192 + (want_local && local_lds <= 24 * 1024 ? local_lds * (size_t)(1024 / block) : 0);
+    const bool deep = may_cull && ctx->accel_usable && !use_fused && stack_bytes_per_thread * 1024 + lds_beside_stacks > ctx->lds_per_cu;
+    int fit_per_cu = 1024 / block;
+    if (deep && !(ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024)) {
+        block = 256;
+        fit_per_cu = 4;
+        for (;;) {
+            if (want_local) plan_local(fit_per_cu);
+            const size_t per_block = stack_bytes_per_thread * 256 + 4096 + (want_local && local_lds <= 24 * 1024 ? local_lds : 0);
+            if (fit_per_cu == 1 || per_block * (size_t)fit_per_cu <= ctx->lds_per_cu) break;
+            --fit_per_cu;
+        }
     }
+    const int blocks_per_cu = fit_per_cu, waves_per_block = block / 64;
+    bool local_fits = want_local && local_lds <= 24 * 1024;       // (deep queues after overflows: the launch-per-pass path takes over)
     P.S.stack_shift = block == 256 ? 8 : (block == 512 ? 9 : 10);
     // LDS per block: the stacks, the material and light tables, then as many top-of-tree nodes as fit
     // beside them when the compute unit holds 1024 threads (the register budget allows four waves per SIMD).
     // A tree so deep that its stacks alone do not fit keeps to the octree walk.
     const size_t lds_block = ctx->lds_per_cu / blocks_per_cu;      // LDS a block may take when a compute unit is full
     size_t lds_stack = (size_t)stack_entries * block * sizeof(int);
-    if (lds_stack + 8192 > ctx->lds_per_cu) bvh_closest_ok = false;     // (a block may take a whole compute unit's LDS)
+    if (lds_stack + 8192 + (local_fits ? local_lds : 0) > ctx->lds_per_cu) bvh_closest_ok = false;     // (a block may take a whole compute unit's LDS)
     if (!bvh_closest_ok) lds_stack = 0;
     const bool bvh_shadow_ok = bvh_closest_ok && !ctx->any_transparent_sphere;
     // every hit record is the 64-byte kind when the scene has no sphere and no triangle is shaded with
