@@ -146,9 +146,11 @@ __device__ inline Box6 fresh_box(const Box6 *p)
 }
 
 // Boxes of the inner nodes, bottom-up: a thread per leaf climbs; at every node the first thread to arrive stops, the second
-// (which then sees both children's boxes) joins them and goes on.
+// (which then sees both children's boxes) joins them and goes on.  With the box goes the node's height: 0 for a subtree of at
+// most `leaf_max` primitives (it becomes a leaf), else one more than its taller child's.
 __global__ __launch_bounds__(256) void k_fit_boxes(const Box6 *item_boxes, const uint32_t *order, int n, const int32_t *left, const int32_t *right,
-                                                   const int32_t *parent_inner, const int32_t *parent_leaf, Box6 *inner_boxes, uint32_t *arrived)
+                                                   const int32_t *first, const int32_t *last, int leaf_max, const int32_t *parent_inner,
+                                                   const int32_t *parent_leaf, Box6 *inner_boxes, int32_t *height, uint32_t *arrived)
 {
     const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (k >= n) return;
@@ -161,6 +163,10 @@ __global__ __launch_bounds__(256) void k_fit_boxes(const Box6 *item_boxes, const
         const Box6 a = lc >= 0 ? fresh_box(inner_boxes + lc) : item_boxes[order[~lc]];
         const Box6 b = rc >= 0 ? fresh_box(inner_boxes + rc) : item_boxes[order[~rc]];
         const Box6 u = join(a, b);
+        const int32_t ha = lc >= 0 ? __hip_atomic_load(height + lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int32_t hb = rc >= 0 ? __hip_atomic_load(height + rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int32_t h = last[node] - first[node] + 1 <= leaf_max ? 0 : 1 + (ha > hb ? ha : hb);
+        __hip_atomic_store(height + node, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float *w = reinterpret_cast<float *>(inner_boxes + node);
         for (int c = 0; c < 3; ++c) {
             __hip_atomic_store(w + c, u.lo[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -178,10 +184,13 @@ struct FoldLevel {
     int32_t *next_count;
     int32_t next_cap;
     int32_t *overflow;
+    int32_t level;               // of this level's nodes (the root's is 0)
+    int32_t levels_wanted;       // the 4-wide tree should have no more levels than this (see k_fold_level)
 };
 
 struct Kid {
     int32_t code;                // >= 0: binary inner node; else leaf code -2 - (first * 4 + count - 1)
+    int32_t height;              // of the binary subtree (0: a leaf)
     Box6 box;
 };
 
@@ -192,9 +201,15 @@ __device__ inline float half_area(const Box6 &b)
 }
 
 // One level of the fold: queue entry q becomes 4-wide node base + q.
+//
+// Which child is opened decides the tree's depth, and the depth the stack a walk needs (three pending siblings a level),
+// which has to fit the LDS beside a full compute unit's waves.  A binary subtree of height h folds into ceil(h / 2) levels
+// when the taller child is opened first (each level then takes two off the height), so a child that could not end within
+// the wanted number of levels even so is opened before the one with the largest box; curve-ordered trees over surfaces are
+// uneven enough for this to matter from a few hundred thousand primitives on.
 __global__ __launch_bounds__(256) void k_fold_level(FoldLevel L, const int32_t *left, const int32_t *right, const int32_t *first, const int32_t *last,
-                                                    const Box6 *inner_boxes, const Box6 *item_boxes, const uint32_t *order, int leaf_max,
-                                                    accel::Bvh4Node *nodes)
+                                                    const Box6 *inner_boxes, const int32_t *height, const Box6 *item_boxes, const uint32_t *order,
+                                                    int leaf_max, accel::Bvh4Node *nodes)
 {
     const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (q >= L.count) return;
@@ -205,10 +220,12 @@ __global__ __launch_bounds__(256) void k_fold_level(FoldLevel L, const int32_t *
         if (c < 0) {
             const int pos = ~c;
             k.code = -2 - (pos * 4);
+            k.height = 0;
             k.box = item_boxes[order[pos]];
         } else {
             const int cnt = last[c] - first[c] + 1;
             k.code = cnt <= leaf_max ? -2 - (first[c] * 4 + (cnt - 1)) : c;
+            k.height = cnt <= leaf_max ? 0 : height[c];
             k.box = inner_boxes[c];
         }
         kids[nk++] = k;
@@ -217,12 +234,17 @@ __global__ __launch_bounds__(256) void k_fold_level(FoldLevel L, const int32_t *
     add(left[me]);
     add(right[me]);
     // open the inner child with the largest box while there is room for its two children
+    const int levels_below = L.levels_wanted - 2 - L.level;      // levels a child of this node may have under it
     while (nk < 4) {
-        int pick = -1;
+        int pick = -1, tall = -1;
         float best = -1.0f;
-        for (int i = 0; i < nk; ++i)
-            if (kids[i].code >= 0 && half_area(kids[i].box) > best) { best = half_area(kids[i].box); pick = i; }
+        for (int i = 0; i < nk; ++i) {
+            if (kids[i].code < 0) continue;
+            if (half_area(kids[i].box) > best) { best = half_area(kids[i].box); pick = i; }
+            if (tall < 0 || kids[i].height > kids[tall].height) tall = i;
+        }
         if (pick < 0) break;
+        if ((kids[tall].height + 1) / 2 > levels_below + 1) pick = tall;
         const int32_t open = kids[pick].code;
         for (int i = pick; i + 1 < nk; ++i) kids[i] = kids[i + 1];
         --nk;

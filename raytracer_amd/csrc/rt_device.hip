@@ -469,6 +469,9 @@ static int scene_alloc(rt_ctx *ctx, size_t n, T **out)
     return RT_OK;
 }
 
+// Twelve levels of three pending siblings each: 36 stack entries and one more, which a compute unit's LDS holds for 1024 threads
+// beside the tables.
+#define LBVH_LEVELS_WANTED 12
 struct DeviceTree {
     const accel::Bvh4Node *nodes = nullptr;
     int32_t n_nodes = 0, max_stack = 0, levels = 0;
@@ -493,7 +496,7 @@ static int lbvh_build(rt_ctx *ctx, hipStream_t st, bool is_tri, const rt_tri_rec
     const size_t N = (size_t)n;
     const size_t o_src = take(N * 4), o_box = take(N * sizeof(lbvh::Box6)), o_code0 = take(N * 8), o_code1 = take(N * 8), o_ord0 = take(N * 4),
                  o_ord1 = take(N * 4), o_left = take(N * 4), o_right = take(N * 4), o_first = take(N * 4), o_last = take(N * 4), o_pin = take(N * 4),
-                 o_pleaf = take(N * 4), o_ibox = take(N * sizeof(lbvh::Box6)), o_arr = take(N * 4), o_q0 = take(N * 4), o_q1 = take(N * 4),
+                 o_pleaf = take(N * 4), o_ibox = take(N * sizeof(lbvh::Box6)), o_height = take(N * 4), o_arr = take(N * 4), o_q0 = take(N * 4), o_q1 = take(N * 4),
                  o_need = take(N * 4), o_ctr = take(64), o_sort = take(sort_bytes);
     unsigned char *ws = nullptr;
     HIP_TRY(hipMalloc((void **)&ws, off));
@@ -506,6 +509,7 @@ static int lbvh_build(rt_ctx *ctx, hipStream_t st, bool is_tri, const rt_tri_rec
             *first = reinterpret_cast<int32_t *>(ws + o_first), *last = reinterpret_cast<int32_t *>(ws + o_last),
             *pin = reinterpret_cast<int32_t *>(ws + o_pin), *pleaf = reinterpret_cast<int32_t *>(ws + o_pleaf);
     uint32_t *arrived = reinterpret_cast<uint32_t *>(ws + o_arr);
+    int32_t *height = reinterpret_cast<int32_t *>(ws + o_height);
     int32_t *queue[2] = {reinterpret_cast<int32_t *>(ws + o_q0), reinterpret_cast<int32_t *>(ws + o_q1)};
     int32_t *need = reinterpret_cast<int32_t *>(ws + o_need), *ctr = reinterpret_cast<int32_t *>(ws + o_ctr);
     HIP_TRY(hipMemcpyAsync(d_src, src.data(), N * 4, hipMemcpyHostToDevice, st));
@@ -520,7 +524,7 @@ static int lbvh_build(rt_ctx *ctx, hipStream_t st, bool is_tri, const rt_tri_rec
     const uint32_t *order = dv.Current();
     hipLaunchKernelGGL(lbvh::k_radix_tree, dim3(nb), dim3(256), 0, st, sorted_codes, n, left, right, first, last, pin, pleaf);
     HIP_TRY(hipMemsetAsync(arrived, 0, N * 4, st));
-    hipLaunchKernelGGL(lbvh::k_fit_boxes, dim3(nb), dim3(256), 0, st, boxes, order, n, left, right, pin, pleaf, iboxes, arrived);
+    hipLaunchKernelGGL(lbvh::k_fit_boxes, dim3(nb), dim3(256), 0, st, boxes, order, n, left, right, first, last, leaf_max, pin, pleaf, iboxes, height, arrived);
     HIP_TRY(hipGetLastError());
     // the fold, level by level from the root (binary inner node 0)
     accel::Bvh4Node *nodes = nullptr;
@@ -528,6 +532,10 @@ static int lbvh_build(rt_ctx *ctx, hipStream_t st, bool is_tri, const rt_tri_rec
     if (rc != RT_OK) return rc;
     const int32_t zero = 0;
     HIP_TRY(hipMemcpyAsync(queue[0], &zero, 4, hipMemcpyHostToDevice, st));
+    // two levels more than a perfectly even tree over the leaves would have, at most LBVH_LEVELS_WANTED
+    int levels_wanted = 2;
+    for (long long leaves = (n + leaf_max - 1) / leaf_max; leaves > 1; leaves = (leaves + 3) / 4) ++levels_wanted;
+    if (levels_wanted > LBVH_LEVELS_WANTED) levels_wanted = LBVH_LEVELS_WANTED;
     std::vector<std::pair<int32_t, int32_t>> levels;      // (first node, nodes)
     int32_t base = 0, count = 1;
     int cur = 0;
@@ -537,7 +545,8 @@ static int lbvh_build(rt_ctx *ctx, hipStream_t st, bool is_tri, const rt_tri_rec
         lbvh::FoldLevel L{};
         L.queue = queue[cur]; L.count = count; L.base = base;
         L.next_queue = queue[cur ^ 1]; L.next_count = ctr; L.next_cap = n; L.overflow = ctr + 1;
-        hipLaunchKernelGGL(lbvh::k_fold_level, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, L, left, right, first, last, iboxes, boxes, order,
+        L.level = (int32_t)levels.size(); L.levels_wanted = levels_wanted;
+        hipLaunchKernelGGL(lbvh::k_fold_level, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, L, left, right, first, last, iboxes, height, boxes, order,
                            leaf_max, nodes);
         int32_t h[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(h, ctr, 8, hipMemcpyDeviceToHost, st));
@@ -582,10 +591,16 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     aopt.verbose = ctx->dbg.verbose;
     aopt.device_min = ctx->dbg.device_build_min;
     const auto t_build = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (ctx->dbg.verbose)
+            fprintf(stderr, "[rt] upload: %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count(), what);
+    };
     accel::build(*s, acc, octree_tri, octree_sph_key, aopt);
+    mark("keys, items and host-built hierarchies");
     if ((rc = upload(ctx, octree_tri.data(), octree_tri.size(), &D.tri)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->sph, (size_t)s->n_sph_slots, &D.sph)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->sph_prim, (size_t)s->n_sph_slots, &D.sph_prim)) != RT_OK) return rc;
+    mark("octree records resident");
     long long n_btri = (long long)acc.tri.size(), n_bsph = (long long)acc.sph.size();
     int stack_tri = acc.tri_bvh4.max_stack, stack_sph = acc.sph_bvh4.max_stack;
     double max_abs = acc.tri_bvh4.max_abs_coord > acc.sph_bvh4.max_abs_coord ? acc.tri_bvh4.max_abs_coord : acc.sph_bvh4.max_abs_coord;
@@ -683,9 +698,7 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
     ctx->accel_usable = usable;
     ctx->n_btri = n_btri;
     ctx->accel_stack = stack_tri > stack_sph ? stack_tri : stack_sph;
-    if (ctx->dbg.verbose)
-        fprintf(stderr, "[rt] hierarchies ready %.1f ms after the upload began their part (%lld triangle and %lld sphere leaf records)\n",
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count(), n_btri, n_bsph);
+    mark("hierarchies resident");
     if ((rc = upload(ctx, s->prim_flags, (size_t)s->n_prims, &D.prim_flags)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->prim_material, (size_t)s->n_prims, &D.prim_material)) != RT_OK) return rc;
     if ((rc = upload(ctx, s->prim_normals, (size_t)s->n_prims * 12, &D.prim_normals)) != RT_OK) return rc;
@@ -767,7 +780,9 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
         ctx->grid_tri_index = const_cast<int32_t *>(d_index);
         ctx->n_grid_tri = (int32_t)first_record.size();
         ctx->n_grid_sph = (int32_t)(acc.sph_on_device ? acc.sph_src.size() : acc.sph.size());
+        mark("primitive, material and light tables resident");
         if ((rc = build_light_grids(ctx, D, ctx->n_grid_sph)) != RT_OK) return rc;
+        mark("lights' grids");
     }
     ctx->S = D;
     ctx->lightcam_samples = s->lightcam_samples;
