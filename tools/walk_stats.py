@@ -14,6 +14,7 @@ fn.argtypes = [C.POINTER(C.c_ulonglong)]
 s = rt.Scene.load(scene_name); g = rt.Renderer(0); g.upload(s); g.set_option("fused", 0)
 cam = s.camera(resx, resy)
 buf = (C.c_ulonglong * 48)()
+g.render(cam, num_samples=N, want=("rgb_u8",))      # (a small frame reads the eye's grid from its camera's second frame on)
 fn(buf)
 fr = g.render(cam, num_samples=N, want=("rgb_u8",))
 fn(buf)
