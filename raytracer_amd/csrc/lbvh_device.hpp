@@ -156,9 +156,11 @@ __global__ __launch_bounds__(256) void k_fit_boxes(const Box6 *item_boxes, const
     if (k >= n) return;
     int node = parent_leaf[k];
     while (node >= 0) {
-        __threadfence();
+        // (boxes and heights are written and read with device-wide atomic accesses, past the caches: that this thread's own
+        // are acknowledged before it announces itself is all the order needed; a device-wide fence would write the L2 back)
+        __threadfence_block();
         if (atomicAdd(&arrived[node], 1u) == 0u) return;
-        __threadfence();
+        __threadfence_block();
         const int32_t lc = left[node], rc = right[node];
         const Box6 a = lc >= 0 ? fresh_box(inner_boxes + lc) : item_boxes[order[~lc]];
         const Box6 b = rc >= 0 ? fresh_box(inner_boxes + rc) : item_boxes[order[~rc]];

@@ -593,9 +593,16 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
     STAMP(2);
     const bool cull = P.cull_shadow != 0;
     WalkCount wc{};
-    for (long long chunk = (GRID && (RT_GRID_BLOCK & (RT_GRID_BLOCK - 1))) ? next_chunk_strided(P.S) : next_chunk(P.S); chunk < (long long)smap.total;
-         chunk = GRID ? next_chunk_strided(P.S) : next_chunk(P.S)) {
-        shadow_chunk<MODE, false, GRID>(P, Q, smap, nl, chunk, stack, cull, wc);
+    if (GRID) {
+        // A wave takes the chunks of all lights of one group of 64 hits, one after the other: the group's records come from
+        // memory once (the later lights' fetches meet them in the compute unit's cache), where chunks dealt out one by one
+        // sent the lights of a group to blocks on different dies, each of which fetched the records for itself.
+        const long long groups = nl ? (long long)(smap.total / nl) : 0;
+        for (long long group = next_chunk_strided(P.S); group < groups; group = next_chunk_strided(P.S))
+            for (uint32_t l = 0; l < nl; ++l) shadow_chunk<MODE, false, GRID>(P, Q, smap, nl, group * nl + l, stack, cull, wc);
+    } else {
+        for (long long chunk = next_chunk(P.S); chunk < (long long)smap.total; chunk = next_chunk(P.S))
+            shadow_chunk<MODE, false, GRID>(P, Q, smap, nl, chunk, stack, cull, wc);
     }
     STAMP(9);
 #ifdef RT_COUNT

@@ -31,6 +31,7 @@
 #include "lightcam_device.hpp"
 #include "viewgrid.hpp"
 #include "lbvh_device.hpp"
+#include "lightcam_paths.hpp"
 #include <hipcub/hipcub.hpp>
 
 // ------------------------------------------------------------------ errors
@@ -84,6 +85,8 @@ struct DebugOptions {
     int rounds = 0;                 // rounds of resident blocks a queued pass is cut into (default 2)
     bool verbose = false;           // device properties, light-camera and splitter statistics on stderr
     int leaf_max = 0, split_budget = -1;   // hierarchy builder (accel::Options), read at the next upload
+    int lightcam_digits = 0;        // > 0: the two-sort builder's keys hold at most this many levels (a deeper tree is then built level by level)
+    int lightcam_levels = 0;        // 1: the device builds the light cameras' trees level by level (lightcam_device.hpp), 0: with two sorts (lightcam_paths.hpp)
     int lightcam_host = 0;          // 1: the light cameras' point octrees are built by the host builder (lightcam_build.cpp)
     int fused = -1;                 // 1: always the one-launch kernel, 0: never, -1: by frame size
     int local_threads = 1024;       // block size of the block-local kernel (256, 512 or 1024)
@@ -987,6 +990,157 @@ static int build_trees_on_device(rt_ctx *ctx, hipStream_t st, lightcam::Point *d
     return RT_OK;
 }
 
+// The same trees with two sorts of the points' whole ways instead of a sort per level (lightcam_paths.hpp).  Returns
+// RT_ERR_UNSUPPORTED (no message) when a tree is deeper than the keys can say: the caller then builds level by level.
+static int build_trees_by_paths(rt_ctx *ctx, hipStream_t st, lightcam::Point *d_pts, const std::vector<int32_t> &h_begins,
+                                const unsigned long long *d_max_bits, void **nodes_out, int32_t *n_nodes_out, void **points_out, int *levels_out)
+{
+    *nodes_out = *points_out = nullptr;
+    *n_nodes_out = 0;
+    const int n_trees = (int)h_begins.size() - 1;
+    const int n_pts = h_begins.back();
+    const size_t n = (size_t)(n_pts > 0 ? n_pts : 1);
+    const size_t cap = 2 * n + 1024 + (size_t)n_trees;
+    lcpath::Params P{};
+    P.n = n_pts;
+    P.n_trees = n_trees;
+    while ((1ll << P.tree_bits) < (long long)n_trees) ++P.tree_bits;
+    P.tree_bits = (P.tree_bits + 3) & ~3;
+    P.digits = (128 - P.tree_bits) / 4;
+    if (P.digits > LCP_MAX_DIGITS) P.digits = LCP_MAX_DIGITS;
+    if (ctx->dbg.lightcam_digits > 0 && ctx->dbg.lightcam_digits < P.digits) P.digits = ctx->dbg.lightcam_digits;
+    const int used_bits = P.tree_bits + 4 * P.digits;                  // of the 128, from the top
+    const int lo_begin = used_bits > 64 ? 128 - used_bits : 64;        // lowest bit of the low word that can be set
+    size_t sort_bytes = 0, scan_bytes = 0;
+    {
+        hipcub::DoubleBuffer<unsigned long long> dk(nullptr, nullptr);
+        hipcub::DoubleBuffer<uint32_t> dv(nullptr, nullptr);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, dk, dv, (int)n, 0, 64, st));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, st));
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_pts = take(n * sizeof(lightcam::Point)), o_w0 = take(n * 8), o_w1 = take(n * 8), o_w2 = take(n * 8), o_w3 = take(n * 8),
+                 o_w4 = take(n * 8), o_i0 = take(n * 4), o_i1 = take(n * 4), o_geo = take(n), o_here = take(n * 4), o_base = take(n * 4),
+                 o_nodes = take(cap * sizeof(lightcam::Node)), o_roots = take((size_t)n_trees * sizeof(lightcam::Node)), o_level = take(cap),
+                 o_list = take(cap * 4), o_small = take(4096), o_sub = take((size_t)n_trees), o_act = take((size_t)n_trees * 4),
+                 o_begins = take((size_t)(n_trees + 1) * 4), o_sort = take(sort_bytes), o_scan = take(scan_bytes);
+    int rc = ws_ensure(&ctx->lc_ws, &ctx->lc_ws_bytes, off);
+    if (rc != RT_OK) return rc;
+    unsigned char *ws = static_cast<unsigned char *>(ctx->lc_ws);
+    lightcam::Point *pts_out = reinterpret_cast<lightcam::Point *>(ws + o_pts);
+    unsigned long long *w[5] = {reinterpret_cast<unsigned long long *>(ws + o_w0), reinterpret_cast<unsigned long long *>(ws + o_w1),
+                                reinterpret_cast<unsigned long long *>(ws + o_w2), reinterpret_cast<unsigned long long *>(ws + o_w3),
+                                reinterpret_cast<unsigned long long *>(ws + o_w4)};
+    uint32_t *ix[2] = {reinterpret_cast<uint32_t *>(ws + o_i0), reinterpret_cast<uint32_t *>(ws + o_i1)};
+    uint8_t *geo = ws + o_geo;
+    uint32_t *here = reinterpret_cast<uint32_t *>(ws + o_here), *base = reinterpret_cast<uint32_t *>(ws + o_base);
+    lightcam::Node *nodes = reinterpret_cast<lightcam::Node *>(ws + o_nodes), *roots = reinterpret_cast<lightcam::Node *>(ws + o_roots);
+    uint8_t *level_of = ws + o_level;
+    int32_t *list = reinterpret_cast<int32_t *>(ws + o_list);
+    // small words: [0] too deep, [1] node overflow, [64..127] nodes per level, [128..191] first of level, [192..255] cursors; LevelCounters at 1024
+    uint32_t *small = reinterpret_cast<uint32_t *>(ws + o_small);
+    lcdev::LevelCounters *ctr = reinterpret_cast<lcdev::LevelCounters *>(ws + o_small + 1024);
+    uint8_t *subdiv = ws + o_sub;
+    int32_t *active = reinterpret_cast<int32_t *>(ws + o_act);
+    int32_t *d_begins = reinterpret_cast<int32_t *>(ws + o_begins);
+    void *sort_ws = ws + o_sort;
+    P.begins = d_begins;
+
+    const unsigned pb = (unsigned)((n + 255) / 256);
+    HIP_TRY(hipMemsetAsync(small, 0, 4096, st));
+    HIP_TRY(hipMemcpyAsync(d_begins, h_begins.data(), (size_t)(n_trees + 1) * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(lcdev::k_roots, dim3((unsigned)((n_trees + 63) / 64)), dim3(64), 0, st, nodes, d_max_bits, d_begins, n_trees, subdiv, ctr, active);
+    HIP_TRY(hipMemcpyAsync(roots, nodes, (size_t)n_trees * sizeof(lightcam::Node), hipMemcpyDeviceToDevice, st));
+    int32_t total_nodes = n_trees;
+    int deepest = 0;
+    if (n_pts > 0) {
+        // a 128-bit sort as two stable 64-bit sorts, low word first; returns where the words and the order ended up
+        auto sort128 = [&](unsigned long long *hi, unsigned long long *lo, unsigned long long *spare_a, unsigned long long *spare_b,
+                           unsigned long long **hi_sorted, unsigned long long **lo_sorted, uint32_t **order) -> int {
+            // `ix[0]` holds the identity on entry
+            hipcub::DoubleBuffer<uint32_t> dv(ix[0], ix[1]);
+            if (lo_begin < 64) {
+                hipLaunchKernelGGL(lcpath::k_gather_words, dim3(pb), dim3(256), 0, st, lo, ix[0], n_pts, spare_a);       // (a copy: the sort may leave its input changed)
+                hipcub::DoubleBuffer<unsigned long long> dk(spare_a, spare_b);
+                size_t sb = sort_bytes;
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_ws, sb, dk, dv, n_pts, lo_begin, 64, st));
+            }
+            hipLaunchKernelGGL(lcpath::k_gather_words, dim3(pb), dim3(256), 0, st, hi, dv.Current(), n_pts, spare_a);
+            hipcub::DoubleBuffer<unsigned long long> dk(spare_a, spare_b);
+            size_t sb = sort_bytes;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_ws, sb, dk, dv, n_pts, 128 - used_bits > 64 ? 128 - used_bits - 64 : 0, 64, st));
+            *hi_sorted = dk.Current();
+            *order = dv.Current();
+            unsigned long long *free_words = dk.Current() == spare_a ? spare_b : spare_a;
+            hipLaunchKernelGGL(lcpath::k_gather_words, dim3(pb), dim3(256), 0, st, lo, dv.Current(), n_pts, free_words);
+            *lo_sorted = free_words;
+            return RT_OK;
+        };
+        // whole ways -> their order -> where the ways end (cleared keys, in the original order)
+        hipLaunchKernelGGL(lcpath::k_paths, dim3(pb), dim3(256), 0, st, P, d_pts, roots, w[0], w[1], ix[0], geo);
+        unsigned long long *hs = nullptr, *ls = nullptr;
+        uint32_t *order = nullptr;
+        if ((rc = sort128(w[0], w[1], w[2], w[3], &hs, &ls, &order)) != RT_OK) return rc;
+        // (the whole keys in w[0], w[1] have been read for the last time: the cleared keys, in the original order, take their place)
+        hipLaunchKernelGGL(lcpath::k_depths, dim3(pb), dim3(256), 0, st, P, hs, ls, order, geo, w[0], w[1], reinterpret_cast<int32_t *>(small));
+        // (the first sort's results in w[2], w[3] and its order are not needed once k_depths has run: the second sort takes the same places)
+        hipLaunchKernelGGL(lcpath::k_iota, dim3(pb), dim3(256), 0, st, ix[0], n_pts);
+        unsigned long long *hf = nullptr, *lf = nullptr;
+        uint32_t *perm = nullptr;
+        if ((rc = sort128(w[0], w[1], w[2], w[3], &hf, &lf, &perm)) != RT_OK) return rc;
+        hipLaunchKernelGGL(lcpath::k_place, dim3(pb), dim3(256), 0, st, P, hf, lf, perm, d_pts, pts_out, here);
+        size_t sc = scan_bytes;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws + o_scan, sc, here, base, n_pts, st));
+        uint32_t last[2] = {0, 0};
+        int32_t flags[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(&last[0], base + (n_pts - 1), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&last[1], here + (n_pts - 1), 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(flags, small, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (flags[0]) return RT_ERR_UNSUPPORTED;
+        if ((size_t)n_trees + (size_t)last[0] + (size_t)last[1] > cap) return fail(RT_ERR_CAPACITY, "light-camera trees: node workspace too small");
+        total_nodes = n_trees + (int32_t)(last[0] + last[1]);
+        HIP_TRY(hipMemsetAsync(level_of, 0, (size_t)n_trees, st));      // (a tree without points keeps the root k_roots made, at level 0)
+        hipLaunchKernelGGL(lcpath::k_nodes, dim3(pb), dim3(256), 0, st, P, hf, lf, base, roots, nodes, (int)cap, level_of, reinterpret_cast<int32_t *>(small) + 1);
+        hipLaunchKernelGGL(lcpath::k_link, dim3(pb), dim3(256), 0, st, P, hf, lf, base, nodes, (int)cap);
+        const unsigned nb = (unsigned)((total_nodes + 255) / 256);
+        hipLaunchKernelGGL(lcpath::k_level_hist, dim3(nb), dim3(256), 0, st, level_of, total_nodes, small + 64);
+        uint32_t per_level[LCP_LEVELS];
+        HIP_TRY(hipMemcpyAsync(per_level, small + 64, sizeof per_level, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(flags, small, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (flags[1]) return fail(RT_ERR_CAPACITY, "light-camera trees: node workspace too small");
+        uint32_t first_of[LCP_LEVELS];
+        uint32_t run = 0;
+        for (int d = 0; d < LCP_LEVELS; ++d) { first_of[d] = run; run += per_level[d]; if (per_level[d]) deepest = d; }
+        if (run != (uint32_t)total_nodes) return fail(RT_ERR_DEVICE, "light-camera trees: the nodes' levels do not add up");
+        HIP_TRY(hipMemcpyAsync(small + 128, first_of, sizeof first_of, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(lcpath::k_level_lists, dim3(nb), dim3(256), 0, st, level_of, total_nodes, small + 128, small + 192, list);
+        for (int d = deepest; d >= 0; --d) {
+            const int count = (int)per_level[d];
+            if (count <= 0) continue;
+            hipLaunchKernelGGL(lcpath::k_finish_list, dim3((unsigned)(count < 4096 ? (count + 3) / 4 : 1024)), dim3(256), 0, st, nodes, list + first_of[d],
+                               count, pts_out);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    void *dn = nullptr, *dp = nullptr;
+    HIP_TRY(hipMalloc(&dn, sizeof(lightcam::Node) * (size_t)total_nodes));
+    if (hipMalloc(&dp, sizeof(lightcam::Point) * n) != hipSuccess) { (void)hipFree(dn); return fail(RT_ERR_DEVICE, "hipMalloc failed for light-camera trees"); }
+    if (hipMemcpyAsync(dn, nodes, sizeof(lightcam::Node) * (size_t)total_nodes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        (n_pts > 0 && hipMemcpyAsync(dp, pts_out, sizeof(lightcam::Point) * (size_t)n_pts, hipMemcpyDeviceToDevice, st) != hipSuccess) ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipFree(dn); (void)hipFree(dp);
+        return fail(RT_ERR_DEVICE, "light-camera trees: copy out of the workspace failed");
+    }
+    *nodes_out = dn;
+    *points_out = dp;
+    *n_nodes_out = total_nodes;
+    if (levels_out) *levels_out = deepest;        // (levels that subdivide, as the level-by-level builder counts them)
+    return RT_OK;
+}
+
 // The table of cameras (one entry per pair, all "not built") and the words the shading passes raise.
 static int ensure_lightcam_table(rt_ctx *ctx, uint32_t lc_flags)
 {
@@ -1110,10 +1264,13 @@ static int build_lightcams(rt_ctx *ctx, const std::vector<int32_t> &pairs, uint3
     void *dn = nullptr, *dp = nullptr;
     int32_t n_nodes = 0;
     int levels = 0;
+    bool by_paths = false;
     std::vector<lightcam::Node> host_nodes;      // (the host builder's output)
     std::vector<lightcam::Point> host_points;
     if (!ctx->dbg.lightcam_host) {
-        rc = build_trees_on_device(ctx, st, ctx->lc_packed, begins, d_meta, &dn, &n_nodes, &dp, &levels);
+        rc = ctx->dbg.lightcam_levels ? RT_ERR_UNSUPPORTED : build_trees_by_paths(ctx, st, ctx->lc_packed, begins, d_meta, &dn, &n_nodes, &dp, &levels);
+        by_paths = rc == RT_OK;
+        if (rc == RT_ERR_UNSUPPORTED) rc = build_trees_on_device(ctx, st, ctx->lc_packed, begins, d_meta, &dn, &n_nodes, &dp, &levels);
         if (rc != RT_OK) return rc;
     } else {
         // host builder: every tree on a thread of its own, the node lists joined behind the roots (root b = node b)
@@ -1170,7 +1327,7 @@ static int build_lightcams(rt_ctx *ctx, const std::vector<int32_t> &pairs, uint3
     if (ctx->dbg.verbose)
         fprintf(stderr, "[rt] %zu light cameras set up in %.2f ms: %d impacts, %d nodes, %d levels (%s builder)\n", n_build,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), begins[n_build], n_nodes, levels,
-                ctx->dbg.lightcam_host ? "host" : "device");
+                ctx->dbg.lightcam_host ? "host" : (by_paths ? "device, two sorts" : "device, level by level"));
     return RT_OK;
 }
 
@@ -2413,6 +2570,8 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "verbose") ctx->dbg.verbose = value != 0;
     else if (n == "leaf_max") ctx->dbg.leaf_max = (int)value;
     else if (n == "split_budget") ctx->dbg.split_budget = (int)value;
+    else if (n == "lightcam_digits") { ctx->dbg.lightcam_digits = (int)value; free_lightcams(ctx); }
+    else if (n == "lightcam_levels") { ctx->dbg.lightcam_levels = (int)value; free_lightcams(ctx); }
     else if (n == "lightcam_host") { ctx->dbg.lightcam_host = (int)value; free_lightcams(ctx); }
     else if (n == "fused") ctx->dbg.fused = (int)value;
     else if (n == "units") ctx->dbg.units = (int)value;

@@ -474,6 +474,28 @@ def test_host_built_light_camera_trees_give_the_same_frame(gpu, oracle_frame):
     assert np.array_equal(g["rgb_u8"], golden)
 
 
+@pytest.mark.parametrize("option,value", [("lightcam_levels", 1), ("lightcam_digits", 9)])
+def test_level_by_level_light_camera_trees_give_the_same_frame(gpu, oracle_frame, option, value):
+    """The device builds the light cameras' point octrees with two sorts of the points' whole ways down the tree; the builder
+    that sorts once per level stays behind `lightcam_levels`, and takes over by itself when a tree is deeper than the keys
+    of the first can say (`lightcam_digits` lowers that depth to one glass.nff's trees exceed).  Either way: hide.ppm."""
+    import gzip
+    import os
+    s = load_scene(gpu, "glass")
+    gpu.set_option(option, value)
+    try:
+        g = gpu.render(s.camera(), flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    finally:
+        gpu.set_option(option, 0)
+    o = oracle_frame("glass")
+    assert_frames_match(g, o, tol=1e-6)
+    assert g["stats"]["lightcam_rays"] == sum(c["light_rays"] for c in o["lightcams"])
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hide.ppm.gz"), "rb") as f:
+        ref = f.read()
+    golden = np.frombuffer(ref[len(b"P6\n900 900\n255\n"):], dtype=np.uint8).reshape(900, 900, 3)
+    assert np.array_equal(g["rgb_u8"], golden)
+
+
 @pytest.mark.parametrize("scene", ["glass3", "glass"])
 def test_one_launch_kernel_with_light_cameras(gpu, oracle_frame, scene):
     s = load_scene(gpu, scene)
