@@ -327,14 +327,19 @@ __global__ __launch_bounds__(256) void k_grid_items(Build B)
         }
 }
 
-// The items with many bins: a block each, its threads striding over the rectangle.
+// The items with many bins: VG_LARGE_SLICES blocks each (a floor under a light covers a whole face of its cube map -- 65 536
+// bins -- and a scene has a handful of such items: one block per item left the rest of the chip idle for 0.4 ms a pass),
+// a block's threads striding over its share of the rectangle.
+#define VG_LARGE_SLICES 32
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_grid_large(Build B)
 {
     uint32_t n = *B.n_large;
     if (n > B.large_cap) n = B.large_cap;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        const uint32_t code = B.large[i];
+    const unsigned long long units = (unsigned long long)n * VG_LARGE_SLICES;
+    for (unsigned long long u = blockIdx.x; u < units; u += gridDim.x) {
+        const uint32_t code = B.large[u / VG_LARGE_SLICES];
+        const uint32_t slice = (uint32_t)(u % VG_LARGE_SLICES);
         const int item = (int)(code >> 3), face = (int)(code & 7u);
         const Shape s = project_item(B, item, face);
         if (s.n == 0) continue;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256) void k_grid_large(Build B)
         const int w = s.bx1 - s.bx0 + 1;
         const long long nb = (long long)w * (s.by1 - s.by0 + 1);
         unsigned long long mine = 0;
-        for (long long k = threadIdx.x; k < nb; k += blockDim.x) {
+        for (long long k = (long long)slice * blockDim.x + threadIdx.x; k < nb; k += (long long)blockDim.x * VG_LARGE_SLICES) {
             const int by = s.by0 + (int)(k / w), bx = s.bx0 + (int)(k - (long long)(by - s.by0) * w);
             if (!bin_touches(B, f, s, bx, by)) continue;
             const uint32_t bin = f.first_bin + (uint32_t)by * (uint32_t)f.nx + (uint32_t)bx;
