@@ -85,6 +85,7 @@ struct DebugOptions {
     int rounds = 0;                 // rounds of resident blocks a queued pass is cut into (default 2)
     bool verbose = false;           // device properties, light-camera and splitter statistics on stderr
     int leaf_max = 0, split_budget = -1;   // hierarchy builder (accel::Options), read at the next upload
+    int stack_min = 0;              // > 0: the walks' stacks get at least this many entries (to run a small scene the way a deep hierarchy runs)
     int lightcam_digits = 0;        // > 0: the two-sort builder's keys hold at most this many levels (a deeper tree is then built level by level)
     int lightcam_levels = 0;        // 1: the device builds the light cameras' trees level by level (lightcam_device.hpp), 0: with two sorts (lightcam_paths.hpp)
     int lightcam_host = 0;          // 1: the light cameras' point octrees are built by the host builder (lightcam_build.cpp)
@@ -1794,6 +1795,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     bool bvh_closest_ok = may_cull && ctx->accel_usable;
     // the builder's bound on pending siblings, plus one (BVH_STACK is the cap the builder checks against)
     int stack_entries = ctx->accel_stack + 1;
+    if (stack_entries < ctx->dbg.stack_min) stack_entries = ctx->dbg.stack_min;
     if (stack_entries > BVH_STACK) stack_entries = BVH_STACK;
     if (stack_entries < 4) stack_entries = 4;
     // Block size.  Large batches run one 1024-thread block per compute unit (one LDS copy of the top of the scene
@@ -2570,6 +2572,7 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "verbose") ctx->dbg.verbose = value != 0;
     else if (n == "leaf_max") ctx->dbg.leaf_max = (int)value;
     else if (n == "split_budget") ctx->dbg.split_budget = (int)value;
+    else if (n == "stack_min") ctx->dbg.stack_min = (int)value;
     else if (n == "lightcam_digits") { ctx->dbg.lightcam_digits = (int)value; free_lightcams(ctx); }
     else if (n == "lightcam_levels") { ctx->dbg.lightcam_levels = (int)value; free_lightcams(ctx); }
     else if (n == "lightcam_host") { ctx->dbg.lightcam_host = (int)value; free_lightcams(ctx); }

@@ -97,3 +97,28 @@ def large_scene(side, n_spheres, seed=5):
     cs = rng.uniform(-7.5, 7.5, (n_spheres, 2))
     out.append("".join("s %.17g %.17g %.17g %.17g\n" % (c[0], c[1], 0.75 + 0.1 * rng.random(), 0.01 + 0.03 * rng.random()) for c in cs))
     return "".join(out)
+
+
+@pytest.mark.parametrize("scene,res", [("teapot-3", (512, 512)), ("balls", (400, 400)), ("teapot-3", (2304, 2304))])
+def test_frames_walked_with_deep_stacks(gpu, scene, res):
+    """A hierarchy whose walks need 39 stack entries or more does not fit the LDS of a compute unit full of waves: such frames
+    run in blocks of 256 threads, as many to a compute unit as fit (`stack_min` makes a small scene run that way: the
+    one-launch kernel at 512 x 512, a launch per pass from 4 M samples on).  Same frames as with the stacks the scene needs."""
+    s = rt.Scene.load(scene)
+    gpu.set_option("device_build_min", 50000)
+    gpu.set_option("grid", 0)
+    gpu.upload(s)
+    cam = s.camera(*res)
+    a = gpu.render(cam, flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    try:
+        for entries in (40, 64):
+            gpu.set_option("stack_min", entries)
+            b = gpu.render(cam, flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+            assert np.array_equal(a["hit_id"], b["hit_id"]) and np.array_equal(a["rgb_u8"], b["rgb_u8"])
+            assert np.abs(a["rgb_f64"] - b["rgb_f64"]).max() <= 1e-9
+            assert a["stats"]["closest_rays"] == b["stats"]["closest_rays"] and a["stats"]["shadow_rays"] == b["stats"]["shadow_rays"]
+            assert b["stats"]["queue_overflow"] == 0
+    finally:
+        gpu.set_option("stack_min", 0)
+        gpu.set_option("grid", 1)
+    s.close()
