@@ -587,7 +587,8 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
     STAMP_RESET();
     // work items are (hit, light) pairs: per 64 hits of a shard one chunk for each light
     const ShardMap smap = shard_map_by_light(&Q.counts[CNT_HITS(Q.generation)], Q.hit_shard_cap, nl);
-    if ((long long)blockIdx.x * (blockDim.x >> 6) >= (long long)smap.total) return;   // no chunk for this block
+    // no chunk for this block (GRID: a block's t-th share is the group of 64 hits number blockIdx + t * gridDim, all its lights)
+    if (GRID ? (nl == 0 || (long long)blockIdx.x >= (long long)(smap.total / nl)) : (long long)blockIdx.x * (blockDim.x >> 6) >= (long long)smap.total) return;
     STAMP(1);
     fill_node_cache(P.S, BVH);      // (GRID: no nodes are cached, S.tri_cached = S.sph_cached = 0; the leaf records are)
     STAMP(2);

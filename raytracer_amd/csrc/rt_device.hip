@@ -1357,7 +1357,8 @@ static int provide_lightcams(rt_ctx *ctx, uint32_t lc_flags, bool cull, bool may
 // drained once in between, when the number of entries is read.  *bins_out / *entries_out are grown when too small.
 #define VG_LARGE_CAP (1u << 18)
 static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> &builds, size_t total_bins, vg::Bin **bins_out,
-                            size_t *bins_cap, vg::Entry **entries_out, size_t *entries_words, size_t *n_entries_out, size_t max_per_bin)
+                            size_t *bins_cap, vg::Entry **entries_out, size_t *entries_words, size_t *n_entries_out, size_t max_per_bin,
+                            size_t *occupied_out = nullptr)
 {
     const size_t nb = builds.size();
     // Bin counts and list positions are 32-bit: an item that is not listed as large enters at most VG_LARGE_BINS bins, the
@@ -1369,7 +1370,7 @@ static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> 
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)(total_bins + 1), st));
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_bins = take((total_bins + 1) * 4), o_begin = take((total_bins + 1) * 4), o_large = take(nb * VG_LARGE_CAP * 4), o_ctr = take((nb + 1) * 4), o_total = take(8), o_scan = take(scan_bytes);
+    const size_t o_bins = take((total_bins + 1) * 4), o_begin = take((total_bins + 1) * 4), o_large = take(nb * VG_LARGE_CAP * 4), o_ctr = take((nb + 1) * 4), o_total = take(16), o_scan = take(scan_bytes);
     int rc = ws_ensure(&ctx->grid_ws, &ctx->grid_ws_bytes, off);
     if (rc != RT_OK) return rc;
     unsigned char *ws = static_cast<unsigned char *>(ctx->grid_ws);
@@ -1383,7 +1384,7 @@ static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> 
     }
     HIP_TRY(hipMemsetAsync(bins, 0, (total_bins + 1) * 4, st));
     HIP_TRY(hipMemsetAsync(ctr, 0, (nb + 1) * 4, st));
-    HIP_TRY(hipMemsetAsync(ws + o_total, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(ws + o_total, 0, 16, st));
     auto launch = [&](bool fill) {
         for (size_t b = 0; b < nb; ++b) {
             vg::Build &B = builds[b];
@@ -1410,18 +1411,23 @@ static int build_view_grids(rt_ctx *ctx, hipStream_t st, std::vector<vg::Build> 
     HIP_TRY(hipGetLastError());
     size_t sb = scan_bytes;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ws + o_scan, sb, bins, begin, (int)(total_bins + 1), st));
-    uint32_t total = 0, overflow = 0;
+    hipLaunchKernelGGL(vg::k_grid_occupied, dim3((unsigned)((total_bins + 255) / 256)), dim3(256), 0, st, begin, (uint32_t)total_bins,
+                       reinterpret_cast<uint32_t *>(ws + o_total + 8));
+    uint32_t total = 0, overflow = 0, occupied = 0;
     unsigned long long large_total = 0;
     HIP_TRY(hipMemcpyAsync(&total, begin + total_bins, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&overflow, ctr + nb, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&large_total, ws + o_total, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&occupied, ws + o_total + 8, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (occupied_out) *occupied_out = occupied;
     if (overflow) return fail(RT_ERR_CAPACITY, "view grids: too many items that cover many bins");
     if (small_bound + large_total >= (1ull << 31)) return RT_ERR_UNSUPPORTED;
-    // Lists this long are no shorter than what a walk of the hierarchy tests (a dense scene seen through few bins): measured
-    // on 320 000 triangles and 100 000 spheres, 18 entries per tile 0.99 against 1.13 ms, 50 per tile 4.64 against 4.71, 139 per
-    // tile 2.23 against 1.64.
-    if (max_per_bin && (size_t)total > max_per_bin * total_bins) return RT_ERR_UNSUPPORTED;
+    // Lists this long (per bin that holds anything) are no shorter than what a walk of the hierarchy tests -- a dense scene seen
+    // through few bins.  Measured: the eye's grid on 320 000 triangles and 100 000 spheres, 18 entries per tile 0.99 against 1.13 ms,
+    // 50 per tile 4.64 against 4.71, 139 per tile 2.23 against 1.64; the lights' grids at 4096 x 4096, gears.nff with 19.6 per bin
+    // 10.1 against 12.2 ms, tetra.nff (4096 small triangles behind one another) with 36 per bin 1.46 against 1.20.
+    if (max_per_bin && (size_t)total > max_per_bin * (size_t)(occupied ? occupied : 1)) return RT_ERR_UNSUPPORTED;
     if (*entries_words < (size_t)total + 4) {
         (void)hipFree(*entries_out); *entries_out = nullptr; *entries_words = 0;
         const size_t want = (size_t)total + (size_t)total / 4 + 1024;
@@ -1484,9 +1490,9 @@ static int build_light_grids(rt_ctx *ctx, DevScene &D, int n_sph_records)
         B.tri = D.btri;
         B.sph = D.bsph;
     }
-    size_t bins_cap = 0, entries_words = 0, n_entries = 0;
+    size_t bins_cap = 0, entries_words = 0, n_entries = 0, occupied = 0;
     int rc = build_view_grids(ctx, ctx->stream, builds, per_light * (size_t)D.n_lights, &ctx->lg_bins, &bins_cap, &ctx->lg_entries,
-                              &entries_words, &n_entries, ctx->dbg.grid_res > 0 ? 0 : 32);      // (a grid asked for by size is made whatever its lists)
+                              &entries_words, &n_entries, ctx->dbg.grid_res > 0 ? 0 : 24, &occupied);      // (a grid asked for by size is made whatever its lists)
     if (rc != RT_OK) {
         // (no grids: the hierarchies answer; not an error of the upload)
         (void)hipFree(ctx->lg_bins); ctx->lg_bins = nullptr;
@@ -1499,8 +1505,8 @@ static int build_light_grids(rt_ctx *ctx, DevScene &D, int n_sph_records)
     D.lg_entries = ctx->lg_entries;
     D.lg_res = res;
     if (ctx->dbg.verbose)
-        fprintf(stderr, "[rt] light grids: %d lights x 6 x %d^2 bins, %zu entries (%.2f per bin), %.2f ms\n", D.n_lights, res, n_entries,
-                (double)n_entries / (double)(per_light * (size_t)D.n_lights),
+        fprintf(stderr, "[rt] light grids: %d lights x 6 x %d^2 bins, %zu entries (%.2f per bin, %.2f per bin that holds any), %.2f ms\n", D.n_lights, res, n_entries,
+                (double)n_entries / (double)(per_light * (size_t)D.n_lights), (double)n_entries / (double)(occupied ? occupied : 1),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     return RT_OK;
 }

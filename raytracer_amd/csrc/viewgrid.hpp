@@ -396,6 +396,14 @@ __global__ __launch_bounds__(256) void k_grid_sort(const uint32_t *begin, uint32
     }
 }
 
+// Bins that hold anything (for the decision whether the lists are short enough to be worth reading).
+__global__ __launch_bounds__(256) void k_grid_occupied(const uint32_t *begin, uint32_t n_bins, uint32_t *occupied)
+{
+    const uint32_t bin = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = __syncthreads_count(bin < n_bins && begin[bin + 1] > begin[bin]);
+    if (threadIdx.x == 0 && n) atomicAdd(occupied, (uint32_t)n);
+}
+
 // The bins' heads, from the offsets and the sorted lists.
 __global__ __launch_bounds__(256) void k_grid_heads(const uint32_t *begin, uint32_t n_bins, const Entry *entries, Bin *bins)
 {
