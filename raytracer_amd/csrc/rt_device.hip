@@ -624,12 +624,28 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
         }
         const int leaf_tri = (aopt.leaf_max >= 1 && aopt.leaf_max <= 4) ? aopt.leaf_max : 2;
         const int leaf_sph = (aopt.leaf_max >= 1 && aopt.leaf_max <= 4) ? aopt.leaf_max : 1;
+        // A tree whose walks would need more stack than a full compute unit's LDS holds (LBVH_LEVELS_WANTED) is built again with
+        // larger leaves, unless the leaf size was asked for: a million triangles at two to a leaf come out at 13 levels and run in
+        // the deep-stack shape (4096 x 4096 frame 107 ms), at three to a leaf at 37 entries (86 ms; the host builder's tree 79 ms).
+        auto build_fitting = [&](bool is_tri, const std::vector<int32_t> &src, int leaf, DeviceTree &t, void **work, const int32_t **d_src,
+                                 const uint32_t **d_order) -> int {
+            for (;;) {
+                const size_t held = ctx->scene_allocs.size();
+                const int brc = lbvh_build(ctx, ctx->stream, is_tri, D.tri, D.sph, src, leaf, sb, t, work, d_src, d_order);
+                if (brc != RT_OK) return brc;
+                const bool asked = aopt.leaf_max >= 1 && aopt.leaf_max <= 4;
+                if (t.max_stack <= 3 * LBVH_LEVELS_WANTED + 1 || asked || leaf >= 4) return RT_OK;
+                (void)hipFree(*work); *work = nullptr;
+                while (ctx->scene_allocs.size() > held) { (void)hipFree(ctx->scene_allocs.back()); ctx->scene_allocs.pop_back(); }
+                ++leaf;
+            }
+        };
         if (acc.tri_on_device) {
             DeviceTree t;
             void *work = nullptr;
             const int32_t *d_src = nullptr;
             const uint32_t *d_order = nullptr;
-            rc = lbvh_build(ctx, ctx->stream, true, D.tri, D.sph, acc.tri_src, leaf_tri, sb, t, &work, &d_src, &d_order);
+            rc = build_fitting(true, acc.tri_src, leaf_tri, t, &work, &d_src, &d_order);
             rt_tri_rec *leaves = nullptr;
             if (rc == RT_OK) rc = scene_alloc(ctx, acc.tri_src.size(), &leaves);
             if (rc == RT_OK) {
@@ -650,7 +666,7 @@ extern "C" int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *s)
             void *work = nullptr;
             const int32_t *d_src = nullptr, *d_keys = nullptr;
             const uint32_t *d_order = nullptr;
-            rc = lbvh_build(ctx, ctx->stream, false, D.tri, D.sph, acc.sph_src, leaf_sph, sb, t, &work, &d_src, &d_order);
+            rc = build_fitting(false, acc.sph_src, leaf_sph, t, &work, &d_src, &d_order);
             rt_sph_rec *leaves = nullptr;
             uint32_t *leaf_prim = nullptr;
             int32_t *leaf_key = nullptr;
@@ -1817,7 +1833,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                                                     !ctx->any_secondary && !(o->flags & RT_FLAG_KEEP_ZERO_WEIGHT)));
     // The block-local one-launch kernel (k_local) takes frames of one batch that are too small to fill the chip pass by
     // pass, in scenes whose trees go on after the first hit and whose shadow queries take the hierarchies.
-    const bool want_local = !noalloc && !use_fused && local_rows > 0 && may_cull && ctx->accel_usable && batch_chunks >= n_chunks &&
+    bool want_local = !noalloc && !use_fused && local_rows > 0 && may_cull && ctx->accel_usable && batch_chunks >= n_chunks &&
                             (ctx->dbg.local == 1 || (ctx->dbg.local < 0 && n_chunks * 64 <= RT_LOCAL_MAX_SAMPLES));
     int block = want_local ? ctx->dbg.local_threads : (noalloc || use_fused || batch_chunks * 64 <= (1ll << 22)) ? 256 : RT_BLOCK;
     // k_local: primary chunks per block (one run per resident wave slot) and the records a block's ray list can hold
@@ -1838,6 +1854,14 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
     };
     if (!use_fused && (ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024)) block = ctx->dbg.block_threads;
     if (want_local) plan_local(1024 / block);
+    // Self-contained blocks whose stacks and lists do not fit a compute unit together give way to a launch per pass (a
+    // 500 000-triangle terrain, 37 entries: 1024 x 1024 frame 6.45 ms in blocks of 256 with three to a compute unit, 4.98 pass by pass).
+    if (want_local && ctx->dbg.local < 0 && (size_t)stack_entries * sizeof(int) * 1024 + 8192 + local_lds * (size_t)(1024 / block) > ctx->lds_per_cu) {
+        want_local = false;
+        local_lds = 0; local_cpb = local_cap = local_grid = 0;
+        block = (noalloc || use_fused || batch_chunks * 64 <= (1ll << 22)) ? 256 : RT_BLOCK;
+        if (!use_fused && (ctx->dbg.block_threads == 256 || ctx->dbg.block_threads == 1024)) block = ctx->dbg.block_threads;
+    }
     // A hierarchy so deep that the stacks of a full compute unit (1024 threads) do not fit its LDS beside the tables (and the
     // lists of k_local) is walked in blocks of 256, as many to a compute unit as their stacks leave room for (three at 40
     // entries): fewer waves in flight, but the hierarchy and not the octree walk, which on a scene large enough to have such
