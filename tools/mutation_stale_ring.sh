@@ -1,4 +1,5 @@
 #!/bin/bash
+# The ring_poison test on the product and on a build without the repair (tools/build_variant.sh stale_ring -DRT_TEST_STALE_RING): the second must fail.
 out=gpurun_out/r3
 mkdir -p $out
 timeout -k 10 300 python -u -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 200 --timeout-method thread -k "stale_ring or units_drawn" > $out/pytest_ring.log 2>&1
