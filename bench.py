@@ -8,7 +8,7 @@ C ABI (scene already resident in HBM), the 8-bit framebuffer is gathered to rank
 (N > 1) and re-ordered into the frame.  Rays = closest-hit rays + shadow rays, counted on
 the device.  Rank 0 prints one JSON line.
 
-Workloads (BASELINE.json `configs`):
+Workloads (the configurations the headline metric and the parity cases are quoted on):
     teapot3_8k16  teapot-3.nff geometry at 7680x4320, -s 4 (16 spp)   [default; the config the
                   1/2/4/8-GPU metric is quoted on; strong scaling over row bands]
     teapot3       teapot-3.nff at its own 512x512, 1 spp
