@@ -231,7 +231,9 @@ int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value);
  * placed there).  rt_group_render takes rt_render's arguments (opts->n_parts and opts->part are ignored) and fills
  * frame-order outputs: device memory of the first listed device when out->on_device, else host memory.  stats: ray
  * counts summed, gpu_ms the slowest member's, kernel times and launches (RT_FLAG_TIMING) summed over the members.
- * rt_group_set_option: "staged" 1 sends every member's part through the copy on the first device (diagnostic). */
+ * rt_group_set_option: "staged" 1 sends every member's part through the copy on the first device (diagnostic);
+ * "rccl" 1 sends the parts as grouped ncclSend / ncclRecv to the first member instead (librccl is loaded at that moment, one
+ * communicator per member: the listed devices must differ; RT_ERR_UNSUPPORTED when they do not or the library is missing). */
 typedef struct rt_group rt_group;
 int rt_group_create(const int *device_ids, int n, rt_group **out);
 int rt_group_destroy(rt_group *g);

@@ -7,10 +7,14 @@
 // a member's part is rendered, a kernel on that member's own stream writes its rows straight into their places of the
 // frame on the first member's device, through peer access over xGMI (every peer has its own link to that device, so the
 // members' writes run side by side, and a member that finishes early does not wait for the others).  Only where two
-// devices cannot reach each other directly does a part go through a copy on the first device.  No collective library is
-// involved: a gather to one root over point-to-point links is N-1 independent transfers.  Not run on more than one GPU
-// so far: the tests drive groups of several contexts on one device.
+// devices cannot reach each other directly does a part go through a copy on the first device.  By default no collective
+// library is involved: a gather to one root over point-to-point links is N-1 independent transfers.  With the option
+// "rccl" the parts travel as grouped ncclSend / ncclRecv instead (librccl is loaded when the option is first used; one
+// communicator per member, made with ncclCommInitAll, so the members' devices must differ): every member sends its part to
+// the first, which receives them into buffers of its own and places the rows from there.  Not run on more than one GPU
+// so far: the tests drive groups of several contexts on one device, and the RCCL form as a group of one.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstring>
 #include <string>
@@ -74,8 +78,42 @@ struct Buffer {
 };
 }  // namespace
 
+// The few entry points of librccl the gather uses, resolved at run time (the library is large, and a process that also
+// runs PyTorch has one loaded already: the same one is then used).
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::vector<void *> comm;                     // per member
+    bool load(std::string *why)
+    {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        if (!lib) { *why = std::string("librccl not found: ") + dlerror(); return false; }
+        auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) *why = std::string("librccl lacks ") + n; return p; };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) { lib = nullptr; return false; }
+        return true;
+    }
+};
+#define RCCL_UINT8 1      // ncclUint8
+
 struct rt_group {
     std::vector<int> devices;
+    Rccl rccl;
+    bool use_rccl = false;                        // option "rccl": the parts travel as ncclSend / ncclRecv
     std::vector<rt_ctx *> ctx;
     hipStream_t stream = nullptr;                 // on the first member's device: the frame's way to host memory; staged parts
     std::vector<hipStream_t> mstream;             // per member, on its device: the placement of its rows
@@ -92,6 +130,8 @@ static const size_t kPixelBytes[4] = {3 * sizeof(double), 3, sizeof(int32_t), 1}
 extern "C" int rt_group_destroy(rt_group *g)
 {
     if (!g) return RT_OK;
+    for (size_t i = 0; i < g->rccl.comm.size(); ++i)
+        if (g->rccl.comm[i]) { (void)hipSetDevice(g->devices[i]); (void)g->rccl.CommDestroy(g->rccl.comm[i]); }
     for (rt_ctx *c : g->ctx) (void)rt_destroy(c);
     for (int k = 0; k < 4; ++k) {
         for (Buffer &b : g->part[k]) b.release();
@@ -147,6 +187,24 @@ extern "C" int rt_group_set_option(rt_group *g, const char *name, int64_t value)
 {
     if (!g || !name) return gfail(RT_ERR_INVALID, "rt_group_set_option: null argument");
     if (std::string(name) == "staged") { g->force_staged = value != 0; return RT_OK; }
+    if (std::string(name) == "rccl") {
+        if (value == 0) { g->use_rccl = false; return RT_OK; }
+        if (g->rccl.comm.empty()) {
+            std::string why;
+            if (!g->rccl.load(&why)) return gfail(RT_ERR_UNSUPPORTED, "rt_group_set_option: rccl: " + why);
+            for (size_t i = 0; i < g->devices.size(); ++i)
+                for (size_t j = 0; j < i; ++j)
+                    if (g->devices[i] == g->devices[j])
+                        return gfail(RT_ERR_UNSUPPORTED, "rt_group_set_option: rccl: a communicator takes a device once, and this group lists device " +
+                                                             std::to_string(g->devices[i]) + " twice");
+            std::vector<void *> comm(g->devices.size(), nullptr);
+            const int e = g->rccl.CommInitAll(comm.data(), (int)g->devices.size(), g->devices.data());
+            if (e != 0) return gfail(RT_ERR_DEVICE, std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(e));
+            g->rccl.comm = comm;
+        }
+        g->use_rccl = true;
+        return RT_OK;
+    }
     return gfail(RT_ERR_INVALID, std::string("rt_group_set_option: unknown option '") + name + "'");
 }
 
@@ -215,7 +273,7 @@ extern "C" int rt_group_render(rt_group *g, const rt_camera *cam, const rt_rende
             frame[k] = static_cast<unsigned char *>(g->frame[k].ptr);
         }
         for (int i = 0; i < n; ++i)
-            if ((!g->direct[(size_t)i] || g->force_staged) && rows[i] > 0) {
+            if ((!g->direct[(size_t)i] || g->force_staged || g->use_rccl) && rows[i] > 0) {
                 int rc = g->staged[k][i].ensure(d0, (size_t)rows[i] * row_bytes[k]);
                 if (rc != RT_OK) return rc;
             }
@@ -230,7 +288,35 @@ extern "C" int rt_group_render(rt_group *g, const rt_camera *cam, const rt_rende
         po.lightcam_mask = dst[3] ? g->part[3][i].ptr : nullptr;
         po.on_device = 1;
         int mrc = rt_render(g->ctx[i], cam, &mo[i], &po, &ms[i]);
-        if (mrc != RT_OK || rows[i] == 0) return mrc;
+        if (mrc != RT_OK) return mrc;
+        if (g->use_rccl) {
+            // Every member sends its part to the first; the first receives all of them (its own too) into its buffers and places
+            // the rows from there.  A member's calls form one group, so none of them waits for another on the host; on the
+            // devices the sends meet their receives when the first member's render is done.
+            Rccl &R = g->rccl;
+            GHIP(hipSetDevice(g->devices[i]));
+            hipStream_t st = g->mstream[i];
+            int e = R.GroupStart();
+            for (int k = 0; k < 4 && e == 0; ++k) {
+                if (!dst[k]) continue;
+                if (rows[i] > 0) e = R.Send(g->part[k][i].ptr, (size_t)rows[i] * row_bytes[k], RCCL_UINT8, 0, R.comm[i], st);
+                if (i == 0)
+                    for (int j = 0; j < n && e == 0; ++j)
+                        if (rows[j] > 0) e = R.Recv(g->staged[k][j].ptr, (size_t)rows[j] * row_bytes[k], RCCL_UINT8, j, R.comm[0], st);
+            }
+            const int e2 = R.GroupEnd();
+            if (e != 0 || e2 != 0) return gfail(RT_ERR_DEVICE, std::string("rccl gather: ") + R.GetErrorString(e != 0 ? e : e2));
+            if (i == 0)
+                for (int k = 0; k < 4; ++k)
+                    for (int j = 0; j < n && dst[k]; ++j)
+                        if (rows[j] > 0)
+                            hipLaunchKernelGGL(k_place_rows, dim3((unsigned)rows[j]), dim3(256), 0, st, static_cast<const unsigned char *>(g->staged[k][j].ptr),
+                                               frame[k], rows[j], (long long)row_bytes[k], band, n, j);
+            GHIP(hipGetLastError());
+            GHIP(hipStreamSynchronize(st));
+            return (int)RT_OK;
+        }
+        if (rows[i] == 0) return mrc;
         const bool direct = g->direct[i] != 0 && !g->force_staged;
         // direct: the member's own device writes the rows to the first device's memory; else the part is copied to the first
         // device and placed there

@@ -30,6 +30,33 @@ def test_group_frame_equals_single_context_and_oracle(oracle_frame, members, ban
     s.close()
 
 
+def test_group_gather_as_rccl_send_and_receive(oracle_frame):
+    """Option `rccl`: the members' parts travel as grouped ncclSend / ncclRecv to the first member, which places the rows.  A
+    communicator takes a device once, so on a one-GPU box this is a group of one (the member sends to itself): the library is
+    loaded, the communicator made, and the frame comes out through send, receive and placement.  A group that lists a device
+    twice is told so."""
+    s = rt.Scene.load("teapot-3")
+    cam = s.camera(150, 133)
+    o = oracle_frame("teapot-3", res=(150, 133))
+    g = rt.Group([0])
+    g.set_option("rccl", 1)
+    g.upload(s)
+    for band in (16, 5):
+        fr = g.render(cam, band_rows=band, flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+        assert np.array_equal(fr["rgb_u8"], o["rgb_u8"])
+        assert np.array_equal(fr["hit_id"], o["hit_id"])
+        assert np.abs(fr["rgb_f64"] - o["rgb_f64"]).max() <= 1e-9
+    g.set_option("rccl", 0)
+    fr = g.render(cam, flags=rt.FLAG_KEEP_ZERO_WEIGHT)
+    assert np.array_equal(fr["rgb_u8"], o["rgb_u8"])
+    g.close()
+    g2 = rt.Group([0, 0])
+    with pytest.raises(rt.RtError, match="twice"):
+        g2.set_option("rccl", 1)
+    g2.close()
+    s.close()
+
+
 def test_group_with_light_cameras_and_device_output(oracle_frame):
     import torch
     s = rt.Scene.load("glass3")
