@@ -1,7 +1,8 @@
 // Command-line host with the reference's interface (Driver.cpp:91-216):
-//     rt_driver [--gpus G] [-s N] [-a A] [-p] input.nff output.ppm
+//     rt_driver [--gpus G] [--rccl] [-s N] [-a A] [-p] input.nff output.ppm
 // Parses the scene, builds the octree, renders through the C ABI -- on GPU 0, or with `--gpus G` as row bands over the
-// first G GPUs of the node (rt_group: the multi-GPU form of the reference's two-thread row split, Driver.cpp:377) --
+// first G GPUs of the node (rt_group: the multi-GPU form of the reference's two-thread row split, Driver.cpp:377; with
+// `--rccl` the bands are gathered as RCCL sends and receives instead of stores through peer access) --
 // and writes a binary PPM.  Unlike the reference (Driver.cpp:727) the output argument is honoured;
 // pass `hide.ppm` to get the reference's file name.
 #include <chrono>
@@ -32,9 +33,11 @@ int main(int argc, char **argv)
     char in_path[4096], out_path[4096];
     // `--gpus G` is this host's own switch: taken out before the reference's argument scanner sees the rest
     int gpus = 1;
+    bool rccl = false;
     std::vector<const char *> args;
     for (int i = 0; i < argc; ++i) {
         if (std::strcmp(argv[i], "--gpus") == 0 && i + 1 < argc) { gpus = std::atoi(argv[++i]); continue; }
+        if (std::strcmp(argv[i], "--rccl") == 0) { rccl = true; continue; }
         args.push_back(argv[i]);
     }
     if (gpus < 1) { std::fprintf(stderr, "--gpus needs a positive number\n"); return 1; }
@@ -54,13 +57,14 @@ int main(int argc, char **argv)
 
     rt_ctx *ctx = nullptr;
     rt_group *group = nullptr;
-    if (gpus > 1) {
+    if (gpus > 1 || rccl) {
         int visible = 0;
         CHECK(rt_device_count(&visible));
         if (gpus > visible) { std::fprintf(stderr, "--gpus %d, but only %d GPU(s) are visible\n", gpus, visible); return 1; }
         std::vector<int> ids;
         for (int i = 0; i < gpus; ++i) ids.push_back(i);
         CHECK(rt_group_create(ids.data(), gpus, &group));
+        if (rccl) CHECK(rt_group_set_option(group, "rccl", 1));
         CHECK(rt_group_upload_scene(group, &desc));
     } else {
         CHECK(rt_create(0, &ctx));

@@ -89,5 +89,8 @@ def test_cli_driver_with_gpus_flag(tmp_path):
     r2 = subprocess.run([driver, rt.scene_path("tetra-3"), str(ref)], capture_output=True, text=True, timeout=120)
     assert r2.returncode == 0
     assert out.read_bytes() == ref.read_bytes()
+    r4 = subprocess.run([driver, "--gpus", "1", "--rccl", rt.scene_path("tetra-3"), str(out)], capture_output=True, text=True, timeout=120)
+    assert r4.returncode == 0, r4.stderr
+    assert out.read_bytes() == ref.read_bytes()
     r3 = subprocess.run([driver, "--gpus", "64", rt.scene_path("tetra-3"), str(out)], capture_output=True, text=True, timeout=120)
     assert r3.returncode != 0 and "GPU" in r3.stderr
