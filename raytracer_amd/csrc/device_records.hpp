@@ -191,6 +191,16 @@ struct QueueSet {
                                      //   block's other counters are in LDS); null: counts + CNT_DEFER(generation)
     uint32_t *commit;                // k_local only: per 64 records of rays_out, how many have been written (a word in LDS each)
     unsigned long long *totals;      // the one-launch kernel only: the frame's ray statistics (16 words)
+    // Records at places that follow from the chunk's number (a primary pass that takes no place from a counter, and the
+    // passes that read what it wrote):
+    uint32_t *direct_counts;         // PRIMARY, or null: chunk c of the batch writes its hits to records c * 64 ... of `hits` and its
+                                     //   rays to records c * 64 * direct_fan ... of `rays_out` (fillers up to whole groups of 64 as with
+                                     //   whole_chunks), and leaves hits | rays << 8 in direct_counts[c]
+    uint32_t direct_fan;             //   groups of 64 ray records a primary chunk can fill (1, or 2 where a hit can spawn two rays)
+    const uint32_t *hit_list;        // a pass that reads `hits`, or null: its k-th group of 64 records is group hit_list[k] of the buffer
+                                     //   (k_compact_direct lists the groups that hold anything and puts their number, times 64, in shard
+                                     //   0's counter; the other shards are empty)
+    const uint32_t *ray_list;        // the same for `rays_in`
 };
 
 // A found primitive is named by its record slot: a triangle slot, or a sphere slot with this bit set.

@@ -113,7 +113,7 @@ DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, i
 // record and the pushes of the hit and of the secondary rays.
 template <bool PRIMARY, bool BVH, bool GRID = false>
 DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &smap, long long chunk, int lane, int *stack, bool cull,
-                       WalkCount &wc, uint32_t shard)
+                       WalkCount &wc, uint32_t shard, uint32_t listed = ~0u)
 {
 #define STAMP_SEL (Q.generation)
     STAMP(10);
@@ -128,7 +128,10 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
         int shard;
         const int local = shard_locate(smap, (uint32_t)chunk, &shard);
         active = local >= 0;
-        const char *rr = rec_at(Q.rays_in, active ? (size_t)shard * Q.in_shard_cap + (uint32_t)local : 0, 5);
+        size_t rslot = active ? (size_t)shard * Q.in_shard_cap + (uint32_t)local : 0;
+        // (groups listed by k_compact_direct; `listed`: the chunk's entry, fetched by the caller while the chunk before was traced)
+        if (Q.ray_list) rslot = (size_t)(listed != ~0u ? listed : Q.ray_list[rslot >> 6]) * 64u + (rslot & 63u);
+        const char *rr = rec_at(Q.rays_in, rslot, 5);
         const rec_v2d r0 = rec_load(rr, 0), r1 = rec_load(rr, 1), r2 = rec_load(rr, 2), r3 = rec_load(rr, 3), r4 = rec_load(rr, 4);
         o = mk3(r0.x, r0.y, r1.x);
         d = mk3(r1.y, r2.x, r2.y);
@@ -206,8 +209,17 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     const uint32_t n_h = (uint32_t)__popcll(mask_h), n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b);
     uint32_t base_h = 0, base_r = 0;
     // places taken: what is pushed, or (whole_chunks) that rounded up to whole chunks, the fillers counted apart for the statistics
-    const bool whole = Q.whole_chunks != 0;
+    // (direct: the places follow from the chunk's number -- no counter is asked, no wave waits for one; whole groups of 64)
+    const bool direct = PRIMARY && Q.direct_counts != nullptr;
+    const bool whole = Q.whole_chunks != 0 || direct;
     const uint32_t take_h = whole ? (n_h + 63u) & ~63u : n_h, take_r = whole ? (n_a + n_b + 63u) & ~63u : n_a + n_b;
+    if (direct) {
+        const uint32_t c = (uint32_t)chunk;      // (a primary chunk's number counts from the batch's first)
+        shard = 0u;
+        base_h = c * 64u;
+        base_r = c * 64u * Q.direct_fan;
+        if (lane == 0) Q.direct_counts[c] = n_h | ((n_a + n_b) << 8);
+    } else
     if (lane == 0) {
         if (n_h) base_h = atomicAdd(&Q.counts[CNT_HITS(Q.generation) + shard], take_h);
         if (n_a + n_b) base_r = atomicAdd(&Q.counts[CNT_RAYS(Q.generation + 1) + shard], take_r);
@@ -223,8 +235,10 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     }
     if (want_refr) dir_a = refract_dir(d, n, m.ior, false);
     if (want_refl) dir_b = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));      // hr.reflectionDir (Solid.h:121-122), only where a ray follows it
-    base_h = (uint32_t)__shfl((int)base_h, 0);
-    base_r = (uint32_t)__shfl((int)base_r, 0);
+    if (!direct) {
+        base_h = (uint32_t)__shfl((int)base_h, 0);
+        base_r = (uint32_t)__shfl((int)base_r, 0);
+    }
     STAMP(7);
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t slot_h = base_h + (uint32_t)__popcll(mask_h & below);
@@ -337,9 +351,11 @@ __global__ __launch_bounds__(GRID ? RT_GRID_BLOCK : RT_BLOCK, GRID ? RT_GRID_WAV
     // unit, not by the block, so that a shard's load does not depend on which blocks were quick.
     const uint32_t G = PRIMARY ? Q.unit_chunks : 0u, gshift = G ? (uint32_t)(31 - __clz((int)G)) : 0u;
     const uint32_t n_units = G ? (uint32_t)((n_chunks + G - 1) >> gshift) : 0u;
+    long long ahead_chunk = -1;
+    uint32_t ahead_listed = ~0u;
     for (;;) {
         long long chunk;
-        uint32_t shard = blockIdx.x & (N_SHARDS - 1);
+        uint32_t shard = blockIdx.x & (N_SHARDS - 1), listed = ~0u;
         if (PRIMARY && G) {
             int t = 0;
             if (lane == 0) t = atomicAdd(&s_lds[P.S.lds_ticket_word], 1);
@@ -379,11 +395,23 @@ __global__ __launch_bounds__(GRID ? RT_GRID_BLOCK : RT_BLOCK, GRID ? RT_GRID_WAV
             chunk = ((long long)id << gshift) + r;
             if (chunk >= n_chunks) continue;
             shard = id & (N_SHARDS - 1);
+        } else if (!PRIMARY && Q.ray_list) {
+            // (a list of groups: the rays lie in shard 0, chunk k of the pass is entry k; the wave's next ticket and its entry
+            // are fetched while this chunk is traced, so the entry is not one more fetch in every chunk's chain)
+            if (ahead_chunk < 0) {
+                ahead_chunk = next_chunk(P.S);
+                ahead_listed = ahead_chunk < n_chunks ? Q.ray_list[ahead_chunk] : ~0u;
+            }
+            chunk = ahead_chunk;
+            listed = ahead_listed;
+            if (chunk >= n_chunks) break;
+            ahead_chunk = next_chunk(P.S);
+            ahead_listed = ahead_chunk < n_chunks ? Q.ray_list[ahead_chunk] : ~0u;
         } else {
             chunk = (GRID && (RT_GRID_BLOCK & (RT_GRID_BLOCK - 1))) ? next_chunk_strided(P.S) : next_chunk(P.S);
             if (chunk >= n_chunks) break;
         }
-        closest_chunk<PRIMARY, BVH, GRID>(P, Q, smap, chunk, lane, stack, cull, wc, shard);
+        closest_chunk<PRIMARY, BVH, GRID>(P, Q, smap, chunk, lane, stack, cull, wc, shard, listed);
     }
     STAMP(9);
 #ifdef RT_COUNT
@@ -392,6 +420,40 @@ __global__ __launch_bounds__(GRID ? RT_GRID_BLOCK : RT_BLOCK, GRID ? RT_GRID_WAV
 #undef STAMP_SEL
 }
 
+
+// After a primary pass with direct placement: the groups of 64 records that hold anything, listed in the order of the chunks
+// (inside a block of 256 chunks; the blocks' runs in the order they arrive), and the counters the next passes and the
+// statistics read, all in shard 0: records listed (groups * 64) and how many of them are fillers.
+__global__ __launch_bounds__(256) void k_compact_direct(const uint32_t *direct_counts, uint32_t n_chunks, uint32_t fan, int generation, uint32_t *counts,
+                                                        uint32_t *hit_list, uint32_t *ray_list)
+{
+    __shared__ uint32_t scan_h[256], scan_r[256], sum_h, sum_r, base_h, base_r;
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t word = c < n_chunks ? direct_counts[c] : 0u;
+    const uint32_t nh = word & 0xffu, nr = word >> 8;
+    const uint32_t gh = nh ? 1u : 0u, gr = (nr + 63u) >> 6;
+    scan_h[threadIdx.x] = gh; scan_r[threadIdx.x] = gr;
+    if (threadIdx.x == 0) sum_h = sum_r = 0u;
+    __syncthreads();
+    if (nh) atomicAdd(&sum_h, nh);
+    if (nr) atomicAdd(&sum_r, nr);
+    for (uint32_t off = 1; off < 256u; off <<= 1) {
+        const uint32_t a = threadIdx.x >= off ? scan_h[threadIdx.x - off] : 0u, b = threadIdx.x >= off ? scan_r[threadIdx.x - off] : 0u;
+        __syncthreads();
+        scan_h[threadIdx.x] += a; scan_r[threadIdx.x] += b;
+        __syncthreads();
+    }
+    if (threadIdx.x == 255) {
+        const uint32_t th = scan_h[255], tr = scan_r[255];
+        base_h = th ? atomicAdd(&counts[CNT_HITS(generation)], th * 64u) >> 6 : 0u;
+        base_r = tr ? atomicAdd(&counts[CNT_RAYS(generation + 1)], tr * 64u) >> 6 : 0u;
+        if (th * 64u != sum_h) atomicAdd(&counts[CNT_PAD_HITS(generation)], th * 64u - sum_h);
+        if (tr * 64u != sum_r) atomicAdd(&counts[CNT_PAD_RAYS(generation + 1)], tr * 64u - sum_r);
+    }
+    __syncthreads();
+    if (gh) hit_list[base_h + scan_h[threadIdx.x] - 1u] = c;
+    for (uint32_t j = 0; j < gr; ++j) ray_list[base_r + scan_r[threadIdx.x] - gr + j] = c * fan + j;
+}
 
 // Diagnostic (option "ring_poison", run before a primary pass that hands its chunks out in units): leaves in every compute
 // unit's LDS, in the four words where that pass keeps its ring of unit numbers, the tags its blocks' units 0..3 wait for --
@@ -446,14 +508,17 @@ DEV int hit_material(const DevScene &S, const char *hr, bool flat, int prim)
 
 template <int MODE, bool SKIP_DARK, bool GRID = false>
 DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &smap, uint32_t nl, long long chunk, int *stack, bool cull,
-                      WalkCount &wc)
+                      WalkCount &wc, uint32_t listed = ~0u)
 {
 #define STAMP_SEL (8 + Q.generation)
     STAMP(10);
     int shard, li;
     const int item = shard_locate_by_light(smap, (uint32_t)chunk, P.div_lights, &shard, &li);      // one light per chunk
     const uint32_t h = item >= 0 ? (uint32_t)item : 0u;
-    const char *hr = rec_at(Q.hits, (size_t)shard * Q.hit_shard_cap + h, Q.hit_stride >> 4);
+    size_t hslot = (size_t)shard * Q.hit_shard_cap + h;
+    // (groups listed by k_compact_direct; `listed`: the group's entry, fetched by the caller while the group before was worked on)
+    if (Q.hit_list) hslot = (size_t)(listed != ~0u ? listed : Q.hit_list[hslot >> 6]) * 64u + (hslot & 63u);
+    const char *hr = rec_at(Q.hits, hslot, Q.hit_stride >> 4);
     // head of the record: P, weight, pixel, prim, material -- four 16-byte pieces fetched together
     const rec_v2d h0 = rec_load(hr, 0), h1 = rec_load(hr, 1), h3 = rec_load(hr, 3);
     const bool active = item >= 0 && ((uint32_t)__double2loint(h3.y) & ~HIT_FLAT) != HIT_NONE;      // (not a record that only fills its chunk up)
@@ -599,8 +664,17 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
         // memory once (the later lights' fetches meet them in the compute unit's cache), where chunks dealt out one by one
         // sent the lights of a group to blocks on different dies, each of which fetched the records for itself.
         const long long groups = nl ? (long long)(smap.total / nl) : 0;
-        for (long long group = next_chunk_strided(P.S); group < groups; group = next_chunk_strided(P.S))
-            for (uint32_t l = 0; l < nl; ++l) shadow_chunk<MODE, false, GRID>(P, Q, smap, nl, group * nl + l, stack, cull, wc);
+        // (with a list of groups -- the hits lie in shard 0 then, group k of the pass is entry k -- the wave's next ticket and
+        // its list entry are fetched while this group is worked on: the entry would be one more fetch in every chunk's chain)
+        long long group = next_chunk_strided(P.S);
+        uint32_t listed = Q.hit_list && group < groups ? Q.hit_list[group] : ~0u;
+        while (group < groups) {
+            const long long after = next_chunk_strided(P.S);
+            const uint32_t listed_after = Q.hit_list && after < groups ? Q.hit_list[after] : ~0u;
+            for (uint32_t l = 0; l < nl; ++l) shadow_chunk<MODE, false, GRID>(P, Q, smap, nl, group * nl + l, stack, cull, wc, listed);
+            group = after;
+            listed = listed_after;
+        }
     } else {
         for (long long chunk = next_chunk(P.S); chunk < (long long)smap.total; chunk = next_chunk(P.S))
             shadow_chunk<MODE, false, GRID>(P, Q, smap, nl, chunk, stack, cull, wc);

@@ -85,6 +85,7 @@ struct DebugOptions {
     int rounds = 0;                 // rounds of resident blocks a queued pass is cut into (default 2)
     bool verbose = false;           // device properties, light-camera and splitter statistics on stderr
     int leaf_max = 0, split_budget = -1;   // hierarchy builder (accel::Options), read at the next upload
+    int direct = 1;                 // the primary pass of a large batch writes its records at places that follow from the chunk's number (0: reserved from counters)
     int stack_min = 0;              // > 0: the walks' stacks get at least this many entries (to run a small scene the way a deep hierarchy runs)
     int lightcam_digits = 0;        // > 0: the two-sort builder's keys hold at most this many levels (a deeper tree is then built level by level)
     int lightcam_levels = 0;        // 1: the device builds the light cameras' trees level by level (lightcam_device.hpp), 0: with two sorts (lightcam_paths.hpp)
@@ -180,6 +181,7 @@ struct rt_ctx {
     rt_camera last_cam{}; bool last_cam_valid = false;        // the camera of the context's last frame of this scene
     int32_t cg_tiles_x = 0;
     void *grid_ws = nullptr; size_t grid_ws_bytes = 0;        // work space of the grid builder (grow-only)
+    void *direct_ws = nullptr; size_t direct_ws_bytes = 0;    // per-chunk counts and group lists of a primary pass with direct placement (grow-only)
     int cu_count = 256;
     int32_t n_materials = 0;
     size_t lds_per_cu = 64 * 1024;   // LDS of one compute unit (maxSharedMemoryPerMultiProcessor)
@@ -343,6 +345,7 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     (void)hipFree(ctx->cg_bins);
     (void)hipFree(ctx->cg_entries);
     (void)hipFree(ctx->grid_ws);
+    (void)hipFree(ctx->direct_ws);
     for (void *p : ctx->stage) (void)hipFree(p);
     for (auto &pr : ctx->ev_closest) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : ctx->ev_shadow) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -2397,6 +2400,31 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.chunk_end = t1;
                 Q.block_row0 = (t0 / (N * N)) / P.blocks_x;
                 Q.block_col0 = (int32_t)((t0 / (N * N)) % P.blocks_x);
+                // Direct placement (QueueSet::direct_counts): the primary pass of a batch that is handed out in units asks no counter
+                // for places -- a quarter of such a pass was the wait for them -- and a small kernel lists the groups of 64 records
+                // that hold anything for the two passes that read them (shadow pass 0, closest-hit pass 1).
+                const long long batch_now = t1 - t0;
+                const uint32_t dfan = ctx->any_transparent ? 2u : 1u;
+                const bool direct = ctx->dbg.direct != 0 && !noalloc && !overlap && QP.unit_chunks != 0 &&
+                                    (long long)hit_cap[0] * N_SHARDS >= batch_now * 64 && (long long)ray_cap[1] * N_SHARDS >= batch_now * 64 * dfan &&
+                                    (long long)hit_cap[0] * N_SHARDS < (1ll << 32) && (long long)ray_cap[1] * N_SHARDS < (1ll << 32);
+                uint32_t *d_counts = nullptr, *d_hit_list = nullptr, *d_ray_list = nullptr;
+                if (direct && g <= 1) {
+                    const size_t need = (size_t)batch_now * 4 * (2 + dfan) + 1024;
+                    int drc = ws_ensure(&ctx->direct_ws, &ctx->direct_ws_bytes, need);
+                    if (drc != RT_OK) return drc;
+                    d_counts = static_cast<uint32_t *>(ctx->direct_ws);
+                    d_hit_list = d_counts + ((batch_now + 63) & ~63ll);
+                    d_ray_list = d_hit_list + ((batch_now + 63) & ~63ll);
+                    if (g == 0) {
+                        Q.direct_counts = d_counts; Q.direct_fan = dfan; Q.hit_list = d_hit_list;
+                        Q.hit_shard_cap = (uint32_t)(hit_cap[0] * N_SHARDS);
+                        Q.out_shard_cap = (uint32_t)(ray_cap[1] * N_SHARDS);
+                    } else {
+                        Q.ray_list = d_ray_list;
+                        Q.in_shard_cap = (uint32_t)(ray_cap[1] * N_SHARDS);
+                    }
+                }
                 if (g >= 2 && P.S.n_lights > 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_s[g - 2], 0));
                 std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
                 if (timing && !(ev = next_event_pair(ctx->ev_closest, ctx->ev_closest_used)))
@@ -2414,6 +2442,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     } else
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
+                    if (Q.direct_counts)
+                        hipLaunchKernelGGL(k_compact_direct, dim3((unsigned)((batch_now + 255) / 256)), dim3(256), 0, st, d_counts, (uint32_t)batch_now, dfan, 0,
+                                           counts, d_hit_list, d_ray_list);
                 } else {
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<false, true>), dim3((unsigned)max_blocks), dim3(block), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<false, false>), dim3((unsigned)max_blocks), dim3(block), lds_closest, st, P, Q);
@@ -2603,6 +2634,7 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "leaf_max") ctx->dbg.leaf_max = (int)value;
     else if (n == "split_budget") ctx->dbg.split_budget = (int)value;
     else if (n == "stack_min") ctx->dbg.stack_min = (int)value;
+    else if (n == "direct") ctx->dbg.direct = (int)value;
     else if (n == "lightcam_digits") { ctx->dbg.lightcam_digits = (int)value; free_lightcams(ctx); }
     else if (n == "lightcam_levels") { ctx->dbg.lightcam_levels = (int)value; free_lightcams(ctx); }
     else if (n == "lightcam_host") { ctx->dbg.lightcam_host = (int)value; free_lightcams(ctx); }
