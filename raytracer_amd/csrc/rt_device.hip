@@ -2291,6 +2291,39 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 hipLaunchKernelGGL(k_poison_ring, dim3(resident), dim3(grid_kernel ? RT_GRID_BLOCK : block), grid_kernel ? lds_grid : lds_closest, st,
                                    (grid_kernel ? Pg.S.lds_ticket_word : P.S.lds_ticket_word) + 4, cnt + CNT_ARRIVED, resident);
             };
+            // Direct placement (QueueSet::direct_counts): the primary pass of a batch that is handed out in units asks no counter
+            // for places -- a quarter of such a pass was the wait for them -- and a small kernel lists the groups of 64 records
+            // that hold anything for the two passes that read them (shadow pass 0, closest-hit pass 1).
+            const long long batch_now = t1 - t0;
+            const uint32_t dfan = ctx->any_transparent ? 2u : 1u;
+            const bool direct = ctx->dbg.direct != 0 && !noalloc && !overlap && QP.unit_chunks != 0 &&
+                                (long long)hit_cap[0] * N_SHARDS >= batch_now * 64 && (long long)ray_cap[1] * N_SHARDS >= batch_now * 64 * dfan &&
+                                (long long)hit_cap[0] * N_SHARDS < (1ll << 32) && (long long)ray_cap[1] * N_SHARDS < (1ll << 32);
+            uint32_t *d_counts = nullptr, *d_hit_list = nullptr, *d_ray_list = nullptr;
+            if (direct) {
+                const size_t need = (size_t)batch_now * 4 * (2 + dfan) + 1024;
+                int drc = ws_ensure(&ctx->direct_ws, &ctx->direct_ws_bytes, need);
+                if (drc != RT_OK) return drc;
+                d_counts = static_cast<uint32_t *>(ctx->direct_ws);
+                d_hit_list = d_counts + ((batch_now + 63) & ~63ll);
+                d_ray_list = d_hit_list + ((batch_now + 63) & ~63ll);
+            }
+            auto apply_direct = [&](QueueSet &Q, int g) {
+                if (!direct) return;
+                if (g == 0) {
+                    Q.direct_counts = d_counts; Q.direct_fan = dfan; Q.hit_list = d_hit_list;
+                    Q.hit_shard_cap = (uint32_t)(hit_cap[0] * N_SHARDS);
+                    Q.out_shard_cap = (uint32_t)(ray_cap[1] * N_SHARDS);
+                } else if (g == 1) {
+                    Q.ray_list = d_ray_list;
+                    Q.in_shard_cap = (uint32_t)(ray_cap[1] * N_SHARDS);
+                }
+            };
+            auto compact_direct = [&](hipStream_t s_) {
+                if (direct)
+                    hipLaunchKernelGGL(k_compact_direct, dim3((unsigned)((batch_now + 255) / 256)), dim3(256), 0, s_, d_counts, (uint32_t)batch_now, dfan, 0, counts,
+                                       d_hit_list, d_ray_list);
+            };
             auto queue_set = [&](int g) {
                 QueueSet Q{};
                 Q.rays_in = B.rays[g & 1];
@@ -2323,6 +2356,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.chunk_end = t1;
                 Q.block_row0 = (t0 / (N * N)) / P.blocks_x;
                 Q.block_col0 = (int32_t)((t0 / (N * N)) % P.blocks_x);
+                apply_direct(Q, g);
                 return Q;
             };
             if (use_pair) {
@@ -2343,6 +2377,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     } else
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
+                    compact_direct(st);
                     if (ev) HIP_TRY(hipEventRecord(ev->second, st));
                 }
                 for (int g = 0; g < 5; ++g) {
@@ -2400,31 +2435,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 Q.chunk_end = t1;
                 Q.block_row0 = (t0 / (N * N)) / P.blocks_x;
                 Q.block_col0 = (int32_t)((t0 / (N * N)) % P.blocks_x);
-                // Direct placement (QueueSet::direct_counts): the primary pass of a batch that is handed out in units asks no counter
-                // for places -- a quarter of such a pass was the wait for them -- and a small kernel lists the groups of 64 records
-                // that hold anything for the two passes that read them (shadow pass 0, closest-hit pass 1).
-                const long long batch_now = t1 - t0;
-                const uint32_t dfan = ctx->any_transparent ? 2u : 1u;
-                const bool direct = ctx->dbg.direct != 0 && !noalloc && !overlap && QP.unit_chunks != 0 &&
-                                    (long long)hit_cap[0] * N_SHARDS >= batch_now * 64 && (long long)ray_cap[1] * N_SHARDS >= batch_now * 64 * dfan &&
-                                    (long long)hit_cap[0] * N_SHARDS < (1ll << 32) && (long long)ray_cap[1] * N_SHARDS < (1ll << 32);
-                uint32_t *d_counts = nullptr, *d_hit_list = nullptr, *d_ray_list = nullptr;
-                if (direct && g <= 1) {
-                    const size_t need = (size_t)batch_now * 4 * (2 + dfan) + 1024;
-                    int drc = ws_ensure(&ctx->direct_ws, &ctx->direct_ws_bytes, need);
-                    if (drc != RT_OK) return drc;
-                    d_counts = static_cast<uint32_t *>(ctx->direct_ws);
-                    d_hit_list = d_counts + ((batch_now + 63) & ~63ll);
-                    d_ray_list = d_hit_list + ((batch_now + 63) & ~63ll);
-                    if (g == 0) {
-                        Q.direct_counts = d_counts; Q.direct_fan = dfan; Q.hit_list = d_hit_list;
-                        Q.hit_shard_cap = (uint32_t)(hit_cap[0] * N_SHARDS);
-                        Q.out_shard_cap = (uint32_t)(ray_cap[1] * N_SHARDS);
-                    } else {
-                        Q.ray_list = d_ray_list;
-                        Q.in_shard_cap = (uint32_t)(ray_cap[1] * N_SHARDS);
-                    }
-                }
+                apply_direct(Q, g);
                 if (g >= 2 && P.S.n_lights > 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_s[g - 2], 0));
                 std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
                 if (timing && !(ev = next_event_pair(ctx->ev_closest, ctx->ev_closest_used)))
@@ -2442,9 +2453,7 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     } else
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
-                    if (Q.direct_counts)
-                        hipLaunchKernelGGL(k_compact_direct, dim3((unsigned)((batch_now + 255) / 256)), dim3(256), 0, st, d_counts, (uint32_t)batch_now, dfan, 0,
-                                           counts, d_hit_list, d_ray_list);
+                    compact_direct(st);
                 } else {
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<false, true>), dim3((unsigned)max_blocks), dim3(block), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<false, false>), dim3((unsigned)max_blocks), dim3(block), lds_closest, st, P, Q);
