@@ -250,8 +250,10 @@ int rt_group_set_option(rt_group *g, const char *name, int64_t value);
  *   kind 3: the node bounding-sphere test (Sphere.h:155-204), `maxT` being the sentinel it returns on a miss;
  *   kind 4: the triangle test as shadow queries use it (hit or not, no quotient formed): t is 0 for a hit, maxT for a miss;
  *   kind 5: the triangle test as nearest-hit queries use it, with `maxT` as the distance of the nearest hit so far
- *           (the test's own upper limit is 1e10): a hit beyond `maxT` may be reported as 1e10.
- * geom: 9 doubles per item (v0, v1, v2) for kinds 0/1/4/5, 4 doubles (centre, radius) for kinds 2/3.
+ *           (the test's own upper limit is 1e10): a hit beyond `maxT` may be reported as 1e10;
+ *   kind 6: the power of the specular term, pow(max(rdir.v, 0), Shine) (Solid.h:166-169), as the kernels form it: t is the power.
+ * geom: 9 doubles per item (v0, v1, v2) for kinds 0/1/4/5, 4 doubles (centre, radius) for kinds 2/3, 4 doubles (base, exponent,
+ * two unused) for kind 6.
  * rays: 6 doubles per item (origin, direction).  out: 4 doubles per item: t (or maxT), then the unit normal
  * for a sphere hit, else zeros.  All pointers are host memory. */
 int rt_debug_intersect(rt_ctx *ctx, int32_t kind, int32_t n, const double *geom, const double *rays, double minT,

@@ -1369,7 +1369,8 @@ __global__ __launch_bounds__(256) void k_finalize(double *accum, long long n_val
 }
 
 // One primitive test per thread with the device functions the kernels use (rt_debug_intersect).  Kinds: 0 triangle,
-// 1 its division-sparing form, 2 sphere, 3 node bound, 4 any-hit triangle form, 5 nearest-hit triangle form with cut-off maxT.
+// 1 its division-sparing form, 2 sphere, 3 node bound, 4 any-hit triangle form, 5 nearest-hit triangle form with cut-off maxT,
+// 6 the power of the specular term (geom: base, exponent, -, -).
 __global__ void k_debug_intersect(int kind, int n, const double *geom, const double *rays, double minT, double maxT, double *out)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -1390,6 +1391,8 @@ __global__ void k_debug_intersect(int kind, int n, const double *geom, const dou
             else if (kind == 4) t = tri_any_fast(ops, o, d, minT, maxT) ? 0.0 : maxT;       // any-hit form: 0 for a hit
             else t = tri_test_fast(ops, o, d, minT, 10000000000.0, maxT);                   // nearest-hit form, maxT is its cut-off
         }
+    } else if (kind == 6) {
+        t = spec_pow(geom[(size_t)i * 4], geom[(size_t)i * 4 + 1]);
     } else if (kind == 2) {
         const double *g = geom + (size_t)i * 4;
         rt_sph_rec sp;

@@ -9,8 +9,8 @@
 //
 // Arithmetic is FP64 in the reference's evaluation order; this file is compiled with
 // -ffp-contract=off so that every +,-,*,/ and sqrt is the same IEEE operation the CPU
-// performs.  Only pow() (specular term) and the order in which a pixel's contributions
-// are summed can differ from a CPU evaluation.
+// performs.  Only the power of the specular term (spec_pow in shading.hpp, a few ulps from pow()) and the order in
+// which a pixel's contributions are summed can differ from a CPU evaluation.
 #include <hip/hip_runtime.h>
 
 #include <array>
@@ -296,7 +296,11 @@ static int create_resources(rt_ctx *ctx, int device_id, const hipDeviceProp_t &p
     HIP_TRY(hipHostMalloc((void **)&ctx->h_totals, RT_TOTALS_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     {
         // a block of the traversal kernels may use all of a compute unit's LDS
+#ifdef RT_STAMP
+        const int lds_max = (int)ctx->lds_per_cu - 16 * 32 * 8;     // (the stamps' own LDS is static)
+#else
         const int lds_max = (int)ctx->lds_per_cu;
+#endif
         const void *kernels[] = {(const void *)k_closest<true, true>,  (const void *)k_closest<true, false>, (const void *)k_closest<false, true>,
                                  (const void *)k_closest<false, false>, (const void *)k_shadow<true>,       (const void *)k_shadow<false>,
                                  (const void *)k_shadow_hybrid,
@@ -360,10 +364,10 @@ extern "C" int rt_destroy(rt_ctx *ctx)
 extern "C" int rt_debug_intersect(rt_ctx *ctx, int32_t kind, int32_t n, const double *geom, const double *rays, double minT,
                                   double maxT, double *out)
 {
-    if (!ctx || !geom || !rays || !out || n < 0 || kind < 0 || kind > 5) return fail(RT_ERR_INVALID, "rt_debug_intersect: bad argument");
+    if (!ctx || !geom || !rays || !out || n < 0 || kind < 0 || kind > 6) return fail(RT_ERR_INVALID, "rt_debug_intersect: bad argument");
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t gdoubles = (size_t)n * ((kind <= 1 || kind >= 4) ? 9 : 4);
+    const size_t gdoubles = (size_t)n * ((kind <= 1 || kind == 4 || kind == 5) ? 9 : 4);
     double *d_geom = nullptr, *d_rays = nullptr, *d_out = nullptr;
     int rc = RT_OK;
     if (hipMalloc((void **)&d_geom, gdoubles * 8) != hipSuccess || hipMalloc((void **)&d_rays, (size_t)n * 48) != hipSuccess ||

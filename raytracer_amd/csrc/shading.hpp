@@ -57,6 +57,56 @@ DEV d3 refract_dir(d3 d, d3 n, double ior, bool renormalize)
     return unit3(add3(d, scale3(2.0 * -dot3(d, nn), nn)));
 }
 
+// The power of the specular term, pow(a, s) for a base that is not negative (a cosine, clamped by the caller), as
+// exp(s log a) from a logarithm and an exponential written for this use (the classic scheme of fdlibm's e_log.c and e_exp.c:
+// argument reduction by the binary exponent, a rational argument and an even polynomial; each below one ulp of error): some
+// 90 vector instructions and few registers where the device library's pow() takes 224 instructions and more registers than
+// anything else in the kernels that shade.  The relative error is at most (3 |s log a| + 2) 2^-53 (the logarithm's ulp and the
+// product's rounding, magnified by the exponential, and the exponential's own ulp) -- where the term can be seen at all
+// (s log a > -36) that is 1.3e-14 of it, and the device library's pow() and the host's differ in the last place already.  pow()'s special values for bases >= 0 are kept: base 0 or infinite, exponent 0, infinite or not a number, base 1.
+DEV double log_of_cosine(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);          // x = 2^k m, m in [1/2, 1); subnormals included
+    int k = __builtin_amdgcn_frexp_exp(x);
+    if (m < 0.70710678118654752440) { m = m + m; k -= 1; }
+    const double f = m - 1.0;                            // exact: m in [sqrt(1/2), sqrt(2))
+    const double q = f / (2.0 + f);
+    const double z = q * q, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                                        6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    // (k ln2 in two parts: the high one has 32 trailing zero bits, so its product with k is exact)
+    const double r = dk * 6.93147180369123816490e-01 - ((hfsq - (q * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+    if (!(x < __builtin_inf())) return x;               // (infinite, or not a number)
+    return x == 0.0 ? -__builtin_inf() : r;
+}
+DEV double exp_of_product(double y)
+{
+    const double kd = __builtin_rint(y * 1.44269504088896338700e+00);
+    const double hi = __builtin_fma(-kd, 6.93147180369123816490e-01, y);
+    const double lo = kd * 1.90821492927058770002e-10;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, 4.13813679705723846039e-08, -1.65339022054652515390e-06),
+                                                                                6.61375632143793436117e-05), -2.77777777770155933842e-03), 1.66666666666666019037e-01);
+    const double e = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    double v = __builtin_amdgcn_ldexp(e, (int)kd);       // (rounds once, also into the subnormals)
+    if (y < -745.2) v = 0.0;
+    if (y > 709.8) v = __builtin_inf();
+    return v;
+}
+DEV double spec_pow(double a, double s)
+{
+#ifdef RT_LIBRARY_POW
+    return pow(a, s);
+#endif
+    const double v = exp_of_product(s * log_of_cosine(a));
+    return (s == 0.0 || a == 1.0) ? 1.0 : v;       // (pow(x, 0) = pow(1, y) = 1 whatever the other operand)
+}
+
 // Diffuse + specular terms of one light at one hit (Solid.h:128-172), scaled by `kfac`
 // (Camera.h:465-476).  `rd` is the unit vector from the hit point to the light.
 // `normal`, `nn`, `v`: the hit record's n, nn and v.
@@ -71,7 +121,7 @@ DEV d3 phong_terms(const rt_material &m, d3 normal, d3 nn, d3 v, const rt_light 
         // and neighbouring lanes are mostly on the same side, so whole waves skip it.
         double pw;
         if (a < 0.0) pw = m.Shine > 0.0 ? 0.0 : (m.Shine == 0.0 ? 1.0 : (m.Shine < 0.0 ? __builtin_inf() : m.Shine));
-        else pw = pow(a, m.Shine);
+        else pw = spec_pow(a, m.Shine);
         double ik = lt->intensity * m.Ks;
         d3 comp = mk3((ik * lt->color[0]) * pw, (ik * lt->color[1]) * pw, (ik * lt->color[2]) * pw);
         local = add3(local, scale3(kfac, comp));
