@@ -252,8 +252,10 @@ int rt_group_set_option(rt_group *g, const char *name, int64_t value);
  *   kind 5: the triangle test as nearest-hit queries use it, with `maxT` as the distance of the nearest hit so far
  *           (the test's own upper limit is 1e10): a hit beyond `maxT` may be reported as 1e10;
  *   kind 6: the power of the specular term, pow(max(rdir.v, 0), Shine) (Solid.h:166-169), as the kernels form it: t is the power.
+ *   kind 7: a vector's normalisation, v / sqrt(v.v) (Eigen's normalized(), e.g. Camera.h:196, Solid.h:119-122), as the kernels
+ *           form it: the unit vector comes back in the three doubles after t.
  * geom: 9 doubles per item (v0, v1, v2) for kinds 0/1/4/5, 4 doubles (centre, radius) for kinds 2/3, 4 doubles (base, exponent,
- * two unused) for kind 6.
+ * two unused) for kind 6, 4 doubles (x, y, z, unused) for kind 7.
  * rays: 6 doubles per item (origin, direction).  out: 4 doubles per item: t (or maxT), then the unit normal
  * for a sphere hit, else zeros.  All pointers are host memory. */
 int rt_debug_intersect(rt_ctx *ctx, int32_t kind, int32_t n, const double *geom, const double *rays, double minT,

@@ -164,6 +164,7 @@ struct FrameParams {
 #define CNT_UNITS (32 * N_SHARDS + 4)            // units of work handed out by a primary pass that shares its chunks out on the device
 #define CNT_LCWORK (32 * N_SHARDS + 5)           // 64-query chunks handed out by the light-camera density pass
 #define CNT_ARRIVED (32 * N_SHARDS + 6)          // blocks of the diagnostic launch that fills the LDS ring words (k_poison_ring)
+#define CNT_FUSED_HITS (32 * N_SHARDS + 7)       // primary hits whose lights were dealt with in the primary pass itself (QueueSet::fused_lights)
 #define CNT_WORDS (32 * N_SHARDS + 16)
 
 struct QueueSet {
@@ -197,6 +198,9 @@ struct QueueSet {
                                      //   rays to records c * 64 * direct_fan ... of `rays_out` (fillers up to whole groups of 64 as with
                                      //   whole_chunks), and leaves hits | rays << 8 in direct_counts[c]
     uint32_t direct_fan;             //   groups of 64 ray records a primary chunk can fill (1, or 2 where a hit can spawn two rays)
+    uint32_t fused_lights;           // PRIMARY with direct_counts, grid-only kernel: the lights' terms of a primary hit are formed in the primary
+                                     //   pass itself (shade_primary_hit) and no hit record is written; such hits are counted in bits 16..23
+                                     //   of direct_counts[c] and reach the statistics through CNT_FUSED_HITS
     const uint32_t *hit_list;        // a pass that reads `hits`, or null: its k-th group of 64 records is group hit_list[k] of the buffer
                                      //   (k_compact_direct lists the groups that hold anything and puts their number, times 64, in shard
                                      //   0's counter; the other shards are empty)

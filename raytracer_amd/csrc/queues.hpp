@@ -18,6 +18,12 @@ DEV int global_row(const FrameParams &P, int local_row)
     return (band * P.n_parts + P.part) * P.band_rows + within;
 }
 
+// Number of set bits of `mask` below this lane's own (two instructions made for it).
+DEV uint32_t rank_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 // Wave-aggregated queue push into this block's shard: one atomic per wave, lanes take
 // consecutive slots.  Returns the record index in the whole queue.
 DEV uint32_t wave_reserve(bool want, uint32_t *shard_counters, uint32_t shard_cap, uint32_t *overflow, bool *ok)
@@ -30,9 +36,9 @@ DEV uint32_t wave_reserve(bool want, uint32_t *shard_counters, uint32_t shard_ca
         int leader = __ffsll((long long)mask) - 1;
         int lane = (int)(threadIdx.x & 63);
         if (lane == leader) base = atomicAdd(&shard_counters[shard], n);
-        base = (uint32_t)__shfl((int)base, leader);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);      // (the leader is the same for every lane: no trip through LDS)
     }
-    uint32_t rank = (uint32_t)__popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
+    uint32_t rank = rank_below(mask);
     uint32_t slot = base + rank;
     *ok = want && slot < shard_cap;
     if (want && slot >= shard_cap) *overflow = 1u;
@@ -61,7 +67,7 @@ DEV ShardMap shard_map(const uint32_t *shard_counters, uint32_t shard_cap, uint3
         if (lane >= off) incl += v;
     }
     m.first = incl - chunks;
-    m.total = (uint32_t)__shfl((int)incl, 63);
+    m.total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     return m;
 }
 // For chunk c (same in all lanes): shard, and this lane's item index inside the shard (or -1).
@@ -69,8 +75,9 @@ DEV int shard_locate(const ShardMap &m, uint32_t c, int *shard_out, int pos_in_c
 {
     const unsigned long long le = __ballot(m.first <= c && m.items > 0);
     const int shard = 63 - __clzll((long long)le);
-    const uint32_t first = (uint32_t)__shfl((int)m.first, shard);
-    const uint32_t items = (uint32_t)__shfl((int)m.items, shard);
+    // (the shard is the same for every lane: its words come by a lane read, not by a trip through LDS)
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)m.first, shard & 63);
+    const uint32_t items = (uint32_t)__builtin_amdgcn_readlane((int)m.items, shard & 63);
     const uint32_t idx = (c - first) * 64u + (uint32_t)(pos_in_chunk >= 0 ? pos_in_chunk : (int)(threadIdx.x & 63));
     *shard_out = shard;
     return idx < items ? (int)idx : -1;
@@ -95,7 +102,7 @@ DEV ShardMap shard_map_by_light(const uint32_t *shard_counters, uint32_t shard_c
         if (lane >= off) incl += v;
     }
     m.first = incl - chunks;
-    m.total = (uint32_t)__shfl((int)incl, 63);
+    m.total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (n_lights == 0) m.items = 0;
     return m;
 }
@@ -105,9 +112,9 @@ DEV int shard_locate_by_light(const ShardMap &m, uint32_t c, const FastDiv &div_
 {
     const unsigned long long le = __ballot(m.first <= c && m.items > 0);
     const int shard = 63 - __clzll((long long)le);
-    const uint32_t first = (uint32_t)__shfl((int)m.first, shard);
-    const uint32_t hits = (uint32_t)__shfl((int)m.items, shard);
-    const uint32_t rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c - first));
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)m.first, shard & 63);
+    const uint32_t hits = (uint32_t)__builtin_amdgcn_readlane((int)m.items, shard & 63);
+    const uint32_t rel = c - first;
     const uint32_t group = fast_div(rel, div_lights);
     *light_out = (int)(rel - group * div_lights.d);
     const uint32_t idx = group * 64u + (uint32_t)(threadIdx.x & 63);
@@ -119,22 +126,27 @@ DEV int shard_locate_by_light(const ShardMap &m, uint32_t c, const FastDiv &div_
 // first and the run's first lane issues the (memory-side) FP64 atomics.  `in_queue` lanes take
 // part in runs even when they contribute nothing (`valid` false), so a shadowed light does not
 // split the run of its hit.
+DEV double lane_down(double v, int byte_address)
+{
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_address, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(byte_address, __double2loint(v)));
+}
 DEV void accum_add_runs(double *accum, bool in_queue, bool valid, uint32_t pixel, double w, d3 c)
 {
     const int lane = (int)(threadIdx.x & 63);
     const uint32_t key = in_queue ? pixel : 0xFFFFFFFFu;
     const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
     const bool head = (lane == 0) || prev != key;
-    // run id = number of run heads at or before this lane: equal ids <=> same contiguous run
+    // the last lane of this lane's run: the one before the next run head above it (runs are contiguous)
     const unsigned long long heads = __ballot(head);
-    const int run = __popcll(heads & ((2ull << lane) - 1ull));
+    const unsigned long long above = heads & ~((2ull << lane) - 1ull);
+    const int run_last = above ? __ffsll((unsigned long long)above) - 2 : 63;
     double vx = valid ? w * c.x : 0.0, vy = valid ? w * c.y : 0.0, vz = valid ? w * c.z : 0.0;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const int orun = __shfl_down(run, off);
-        const bool same = lane + off < 64 && orun == run;
-        if (__ballot(same) == 0) break;      // runs are contiguous: no partner at this distance, none farther
-        const double ox = __shfl_down(vx, off), oy = __shfl_down(vy, off), oz = __shfl_down(vz, off);
+        const bool same = lane + off <= run_last;
+        if (__ballot(same) == 0) break;      // no partner at this distance, none farther
+        const int from = ((lane + off) & 63) << 2;      // (a lane that wraps around has no partner)
+        const double ox = lane_down(vx, from), oy = lane_down(vy, from), oz = lane_down(vz, from);
         if (same) { vx += ox; vy += oy; vz += oz; }
     }
     if (in_queue && head && (vx != 0.0 || vy != 0.0 || vz != 0.0)) {

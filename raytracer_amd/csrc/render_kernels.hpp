@@ -111,7 +111,50 @@ DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, i
 #endif
 // One 64-ray chunk of a closest-hit pass: the rays (generated, or read from the queue), the closest-hit query, the hit
 // record and the pushes of the hit and of the secondary rays.
-template <bool PRIMARY, bool BVH, bool GRID = false>
+// The lights' terms at a primary hit, formed where the hit was found (the grid-only primary kernel of a scene whose shadow
+// queries are order-free and whose lights have grids, FUSE): what shadow_chunk does for a hit record, without the record --
+// the hit is neither written nor read back.  Returns the sum of the terms of the lights that reach the hit (`*lit_any`:
+// there is one): the caller adds it to the pixel in the one run-reduced sum of the chunk.
+DEV d3 shade_primary_hit(const FrameParams &P, bool active, d3 Pt, d3 vv, d3 n2, d3 n3, bool flat, int prim, int mat, WalkCount &wc, bool *lit_any)
+{
+    const int nl = P.S.n_lights;
+    const uint32_t per_light = 6u * (uint32_t)(P.S.lg_res * P.S.lg_res);
+    d3 sum = mk3(0, 0, 0);
+    bool any = false;
+    for (int li = 0; li < nl; ++li) {
+        const d3 lpos = ld3(load_light(P.S, li, true).pos);
+        if (active) {
+            const d3 toL = sub3(lpos, Pt);
+            const d3 rd = unit3(toL);
+            const double maxT = norm3(toL) - .01;
+            const double d2 = dot3(rd, rd);
+            bool occluded = false;
+            if (root_gate(P.S, Pt, rd, d2, 10000000.0)) {
+                WC_ADD(wc, rays);
+                const uint32_t bin = (uint32_t)li * per_light + light_bin(Pt, lpos, P.S.lg_res);
+                occluded = grid_any(P.S, P.S.lg_bins, bin, P.S.lg_entries, Pt, rd, d2, prim, maxT, wc);
+            }
+            if (!occluded) {
+                const rt_light lgt = load_light(P.S, li, true);
+                d3 normal = n2, nn = n3;
+                if (flat) {
+                    const void *src = (const void *)&P.S.prim_n23[(size_t)prim * 6];
+                    const rec_v2d a = tab_load(src, 0), b = tab_load(src, 1), c = tab_load(src, 2);
+                    normal = mk3(a.x, a.y, b.x); nn = mk3(b.y, c.x, c.y);
+                }
+                const d3 local = phong_terms(load_material(P.S, mat, true), normal, nn, vv, &lgt, rd, .999999);
+                sum = any ? add3(sum, local) : local;
+                any = true;
+            }
+        }
+    }
+    *lit_any = any;
+    return sum;
+}
+
+// FUSE (grid-only primary kernel): 1 the lights' terms of a hit are formed here, 2 the same for a scene whose hits are all
+// flat triangles' (no normals held through the queries).
+template <bool PRIMARY, bool BVH, bool GRID = false, int FUSE = 0>
 DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &smap, long long chunk, int lane, int *stack, bool cull,
                        WalkCount &wc, uint32_t shard, uint32_t listed = ~0u)
 {
@@ -194,18 +237,19 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     // misses add the background (placed after the hit's table fetches have been issued, so that their
     // latency runs beside the shuffles and atomics of this sum)
     STAMP(5);
-    accum_add_runs(P.accum, active, active && !hit, pixel, wloc, ld3(P.S.bg));
+    if (!(PRIMARY && GRID && FUSE != 0)) accum_add_runs(P.accum, active, active && !hit, pixel, wloc, ld3(P.S.bg));      // (FUSE: below, with the lights' terms)
     STAMP(6);
 
     // Queue pushes.  The three reservations (hit record, refraction ray, reflection ray) are made
     // with two atomics -- both kinds of ray go to the same queue -- issued back to back by one lane,
     // so a wave waits for one round trip to the counters instead of three in a row.
     const bool want_hit = hit && P.S.n_lights > 0;
+    constexpr bool fuse = PRIMARY && GRID && FUSE != 0;      // (the lights' terms are formed below: no hit record)
     const bool spawn = hit && L > 0 && !(coef < .01);       // Camera.h:244-307
     const double coef2 = coef * m.Ks;
     const bool want_refr = spawn && m.T > 0;
     const bool want_refl = spawn && (coef2 != 0.0 || (P.flags & RT_FLAG_KEEP_ZERO_WEIGHT));
-    const unsigned long long mask_h = __ballot(want_hit), mask_a = __ballot(want_refr), mask_b = __ballot(want_refl);
+    const unsigned long long mask_h = __ballot(want_hit && !fuse), mask_a = __ballot(want_refr), mask_b = __ballot(want_refl);
     const uint32_t n_h = (uint32_t)__popcll(mask_h), n_a = (uint32_t)__popcll(mask_a), n_b = (uint32_t)__popcll(mask_b);
     uint32_t base_h = 0, base_r = 0;
     // places taken: what is pushed, or (whole_chunks) that rounded up to whole chunks, the fillers counted apart for the statistics
@@ -218,7 +262,8 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
         shard = 0u;
         base_h = c * 64u;
         base_r = c * 64u * Q.direct_fan;
-        if (lane == 0) Q.direct_counts[c] = n_h | ((n_a + n_b) << 8);
+        const uint32_t n_f = fuse ? (uint32_t)__popcll(__ballot(want_hit)) : 0u;      // (hits whose lights are dealt with below)
+        if (lane == 0) Q.direct_counts[c] = n_h | ((n_a + n_b) << 8) | (n_f << 16);
     } else
     if (lane == 0) {
         if (n_h) base_h = atomicAdd(&Q.counts[CNT_HITS(Q.generation) + shard], take_h);
@@ -236,15 +281,14 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     if (want_refr) dir_a = refract_dir(d, n, m.ior, false);
     if (want_refl) dir_b = unit3(add3(d, scale3(2.0 * -dot3(d, n), n)));      // hr.reflectionDir (Solid.h:121-122), only where a ray follows it
     if (!direct) {
-        base_h = (uint32_t)__shfl((int)base_h, 0);
-        base_r = (uint32_t)__shfl((int)base_r, 0);
+        base_h = (uint32_t)__builtin_amdgcn_readlane((int)base_h, 0);
+        base_r = (uint32_t)__builtin_amdgcn_readlane((int)base_r, 0);
     }
     STAMP(7);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const uint32_t slot_h = base_h + (uint32_t)__popcll(mask_h & below);
-    const uint32_t slot_a = base_r + (uint32_t)__popcll(mask_a & below);
-    const uint32_t slot_b = base_r + n_a + (uint32_t)__popcll(mask_b & below);
-    if ((want_hit && slot_h >= Q.hit_shard_cap) || (want_refr && slot_a >= Q.out_shard_cap) ||
+    const uint32_t slot_h = base_h + rank_below(mask_h);
+    const uint32_t slot_a = base_r + rank_below(mask_a);
+    const uint32_t slot_b = base_r + n_a + rank_below(mask_b);
+    if ((want_hit && !fuse && slot_h >= Q.hit_shard_cap) || (want_refr && slot_a >= Q.out_shard_cap) ||
         (want_refl && slot_b >= Q.out_shard_cap))
         Q.counts[CNT_OVERFLOW] = 1u;
 
@@ -260,7 +304,7 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
             rec_store(rec_at(Q.rays_out, (size_t)shard * Q.out_shard_cap + fill_r, 5), 4, q);
         }
     }
-    if (want_hit && slot_h < Q.hit_shard_cap) {
+    if (want_hit && !fuse && slot_h < Q.hit_shard_cap) {
         char *dst = rec_at(Q.hits, (size_t)shard * Q.hit_shard_cap + slot_h, Q.hit_stride >> 4);
         // HitRec: P, v, weight, pixel, prim -- and for a hit whose normal is not its primitive's tabulated one
         // (a sphere, interpolated vertex normals) the material and the normal normalised twice and thrice
@@ -298,13 +342,25 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
         }
     }
     STAMP(8);
+    if (PRIMARY && GRID) {
+        // (a scene whose hits are all flat triangles' takes the normals from the primitives' table: none held)
+        // (a sample adds either the background or the sum of its lights' terms: one run-reduced sum for the chunk)
+        if (FUSE != 0) {
+            bool lit_any = false;
+            d3 terms;
+            if (FUSE == 2) terms = shade_primary_hit(P, want_hit, Pt, vv, mk3(0, 0, 0), mk3(0, 0, 0), true, prim, mat, wc, &lit_any);
+            else terms = shade_primary_hit(P, want_hit, Pt, vv, n2, n3, flat, prim, mat, wc, &lit_any);
+            const d3 bg = ld3(P.S.bg);
+            accum_add_runs(P.accum, active, active && (!hit || lit_any), pixel, wloc, hit ? terms : bg);
+        }
+    }
 
 #undef STAMP_SEL
 }
 
 // GRID: the primary pass of a frame whose eye has a grid (viewgrid.hpp), as a kernel of its own: no hierarchy walk is
 // compiled in, so it needs no traversal stacks in LDS and fewer registers (blocks of RT_GRID_BLOCK threads).
-template <bool PRIMARY, bool BVH, bool GRID = false>
+template <bool PRIMARY, bool BVH, bool GRID = false, int FUSE = 0>
 __global__ __launch_bounds__(GRID ? RT_GRID_BLOCK : RT_BLOCK, GRID ? RT_GRID_WAVES : RT_MIN_WAVES) void k_closest(FrameParams P, QueueSet Q)
 {
 #define STAMP_SEL (Q.generation)
@@ -411,7 +467,7 @@ __global__ __launch_bounds__(GRID ? RT_GRID_BLOCK : RT_BLOCK, GRID ? RT_GRID_WAV
             chunk = (GRID && (RT_GRID_BLOCK & (RT_GRID_BLOCK - 1))) ? next_chunk_strided(P.S) : next_chunk(P.S);
             if (chunk >= n_chunks) break;
         }
-        closest_chunk<PRIMARY, BVH, GRID>(P, Q, smap, chunk, lane, stack, cull, wc, shard, listed);
+        closest_chunk<PRIMARY, BVH, GRID, FUSE>(P, Q, smap, chunk, lane, stack, cull, wc, shard, listed);
     }
     STAMP(9);
 #ifdef RT_COUNT
@@ -427,16 +483,17 @@ __global__ __launch_bounds__(GRID ? RT_GRID_BLOCK : RT_BLOCK, GRID ? RT_GRID_WAV
 __global__ __launch_bounds__(256) void k_compact_direct(const uint32_t *direct_counts, uint32_t n_chunks, uint32_t fan, int generation, uint32_t *counts,
                                                         uint32_t *hit_list, uint32_t *ray_list)
 {
-    __shared__ uint32_t scan_h[256], scan_r[256], sum_h, sum_r, base_h, base_r;
+    __shared__ uint32_t scan_h[256], scan_r[256], sum_h, sum_r, sum_f, base_h, base_r;
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     const uint32_t word = c < n_chunks ? direct_counts[c] : 0u;
-    const uint32_t nh = word & 0xffu, nr = word >> 8;
+    const uint32_t nh = word & 0xffu, nr = (word >> 8) & 0xffu, nf = word >> 16;       // (nf: hits shaded where they were found)
     const uint32_t gh = nh ? 1u : 0u, gr = (nr + 63u) >> 6;
     scan_h[threadIdx.x] = gh; scan_r[threadIdx.x] = gr;
-    if (threadIdx.x == 0) sum_h = sum_r = 0u;
+    if (threadIdx.x == 0) sum_h = sum_r = sum_f = 0u;
     __syncthreads();
     if (nh) atomicAdd(&sum_h, nh);
     if (nr) atomicAdd(&sum_r, nr);
+    if (nf) atomicAdd(&sum_f, nf);
     for (uint32_t off = 1; off < 256u; off <<= 1) {
         const uint32_t a = threadIdx.x >= off ? scan_h[threadIdx.x - off] : 0u, b = threadIdx.x >= off ? scan_r[threadIdx.x - off] : 0u;
         __syncthreads();
@@ -449,6 +506,7 @@ __global__ __launch_bounds__(256) void k_compact_direct(const uint32_t *direct_c
         base_r = tr ? atomicAdd(&counts[CNT_RAYS(generation + 1)], tr * 64u) >> 6 : 0u;
         if (th * 64u != sum_h) atomicAdd(&counts[CNT_PAD_HITS(generation)], th * 64u - sum_h);
         if (tr * 64u != sum_r) atomicAdd(&counts[CNT_PAD_RAYS(generation + 1)], tr * 64u - sum_r);
+        if (sum_f) atomicAdd(&counts[CNT_FUSED_HITS], sum_f);
     }
     __syncthreads();
     if (gh) hit_list[base_h + scan_h[threadIdx.x] - 1u] = c;
@@ -506,9 +564,17 @@ DEV int hit_material(const DevScene &S, const char *hr, bool flat, int prim)
     return __double2loint(rec_load(hr, 4).y);       // (HitRec::mat: the third word of piece 4)
 }
 
+// What the chunks of one group of 64 hits -- one chunk per light, the same hits in the same lanes -- add to their pixels,
+// summed per lane over the lights, so that the group needs one run-reduced sum instead of one per light.
+struct GroupTerms {
+    d3 sum;
+    bool any, active;
+    uint32_t pixel;
+    double weight;
+};
 template <int MODE, bool SKIP_DARK, bool GRID = false>
 DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &smap, uint32_t nl, long long chunk, int *stack, bool cull,
-                      WalkCount &wc, uint32_t listed = ~0u)
+                      WalkCount &wc, uint32_t listed = ~0u, GroupTerms *group = nullptr)
 {
 #define STAMP_SEL (8 + Q.generation)
     STAMP(10);
@@ -632,7 +698,12 @@ DEV void shadow_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &s
     if (__ballot(lit && local.x > 1e300) == 0xdeadbeefull) return;      // (the terms are formed)
 #endif
     STAMP(5);
-    accum_add_runs(P.accum, active, lit, pixel, weight, local);
+    if (group) {
+        if (lit) { group->sum = group->any ? add3(group->sum, local) : local; group->any = true; }
+        group->active = active; group->pixel = pixel; group->weight = weight;
+    } else {
+        accum_add_runs(P.accum, active, lit, pixel, weight, local);
+    }
     STAMP(8);
 
 #undef STAMP_SEL
@@ -671,7 +742,10 @@ DEV void shadow_pass(const FrameParams &P, const QueueSet &Q)
         while (group < groups) {
             const long long after = next_chunk_strided(P.S);
             const uint32_t listed_after = Q.hit_list && after < groups ? Q.hit_list[after] : ~0u;
-            for (uint32_t l = 0; l < nl; ++l) shadow_chunk<MODE, false, GRID>(P, Q, smap, nl, group * nl + l, stack, cull, wc, listed);
+            GroupTerms terms;
+            terms.sum = mk3(0, 0, 0); terms.any = terms.active = false; terms.pixel = 0u; terms.weight = 0.0;
+            for (uint32_t l = 0; l < nl; ++l) shadow_chunk<MODE, false, GRID>(P, Q, smap, nl, group * nl + l, stack, cull, wc, listed, &terms);
+            accum_add_runs(P.accum, terms.active, terms.any, terms.pixel, terms.weight, terms.sum);
             group = after;
             listed = listed_after;
         }
@@ -1330,6 +1404,7 @@ DEV void collect_counts(const uint32_t *counts, unsigned long long *totals, int 
             h += __shfl_down(h, off);
         }
         if (lane == 0) {
+            if (g == 0) h += counts[CNT_FUSED_HITS];        // (primary hits shaded where they were found: no records, the same rays)
             totals[2 + g] += r;
             totals[8 + g] += h;
             totals[0] += r;
@@ -1370,7 +1445,8 @@ __global__ __launch_bounds__(256) void k_finalize(double *accum, long long n_val
 
 // One primitive test per thread with the device functions the kernels use (rt_debug_intersect).  Kinds: 0 triangle,
 // 1 its division-sparing form, 2 sphere, 3 node bound, 4 any-hit triangle form, 5 nearest-hit triangle form with cut-off maxT,
-// 6 the power of the specular term (geom: base, exponent, -, -).
+// 6 the power of the specular term (geom: base, exponent, -, -), 7 a vector's normalisation (geom: x, y, z, -; the unit
+// vector comes back where a sphere's normal does).
 __global__ void k_debug_intersect(int kind, int n, const double *geom, const double *rays, double minT, double maxT, double *out)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -1393,6 +1469,8 @@ __global__ void k_debug_intersect(int kind, int n, const double *geom, const dou
         }
     } else if (kind == 6) {
         t = spec_pow(geom[(size_t)i * 4], geom[(size_t)i * 4 + 1]);
+    } else if (kind == 7) {
+        nrm = unit3(ld3(geom + (size_t)i * 4));
     } else if (kind == 2) {
         const double *g = geom + (size_t)i * 4;
         rt_sph_rec sp;

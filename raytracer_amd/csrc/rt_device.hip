@@ -103,6 +103,7 @@ struct DebugOptions {
     long long device_build_min = 50000;   // hierarchies over at least this many primitives are built on the device (0: never); read at the next upload
     int grid = 1;                   // 0: no grids, every query walks the hierarchies; 1: lights' and eye's grids (viewgrid.hpp); 2: lights only; 3: eye only
     int grid_kernels = 1;           // 0: the passes that read the grids run in the general kernels (1024-thread blocks)
+    int fuse_lights = 1;            // 0: the primary pass writes hit records for a shadow pass of its own even where it could shade them itself
     int grid_res = 0;               // bins per edge of a face of a light's cube map (0: default)
     long long grid_min_samples = -1; // the eye's grid is made for frames of at least this many samples (-1: default)
     int ring_poison = 0;            // 1: before a primary pass that hands out units, the LDS ring words of every compute unit are filled with
@@ -309,7 +310,8 @@ static int create_resources(rt_ctx *ctx, int device_id, const hipDeviceProp_t &p
                                  (const void *)k_local<SHADOW_BVH>, (const void *)k_local<SHADOW_HYBRID>,
                                  (const void *)k_fused<true, SHADOW_BVH>, (const void *)k_fused<true, SHADOW_HYBRID>,
                                  (const void *)k_fused<true, SHADOW_EXACT>, (const void *)k_fused<false, SHADOW_EXACT>,
-                                 (const void *)k_poison_ring, (const void *)k_closest<true, true, true>, (const void *)k_shadow_grid};
+                                 (const void *)k_poison_ring, (const void *)k_closest<true, true, true>, (const void *)k_closest<true, true, true, 1>,
+                                 (const void *)k_closest<true, true, true, 2>, (const void *)k_shadow_grid};
         for (const void *k : kernels) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     }
     if (device_id < RT_MAX_DEVICES) {
@@ -364,7 +366,7 @@ extern "C" int rt_destroy(rt_ctx *ctx)
 extern "C" int rt_debug_intersect(rt_ctx *ctx, int32_t kind, int32_t n, const double *geom, const double *rays, double minT,
                                   double maxT, double *out)
 {
-    if (!ctx || !geom || !rays || !out || n < 0 || kind < 0 || kind > 6) return fail(RT_ERR_INVALID, "rt_debug_intersect: bad argument");
+    if (!ctx || !geom || !rays || !out || n < 0 || kind < 0 || kind > 7) return fail(RT_ERR_INVALID, "rt_debug_intersect: bad argument");
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t gdoubles = (size_t)n * ((kind <= 1 || kind == 4 || kind == 5) ? 9 : 4);
@@ -2312,10 +2314,15 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 d_hit_list = d_counts + ((batch_now + 63) & ~63ll);
                 d_ray_list = d_hit_list + ((batch_now + 63) & ~63ll);
             }
+            // ... and where the primary pass is the grid-only kernel and the shadow pass would be too, the primary pass deals with
+            // the lights at its hits itself: no hit records, no shadow pass for generation 0 (QueueSet::fused_lights)
+            const bool fuse0 = direct && ctx->dbg.fuse_lights != 0 && grid_kernels && P.cg_bins && bvh_closest_ok && bvh_shadow_ok && P.S.lg_bins &&
+                               P.S.n_lights > 0;
             auto apply_direct = [&](QueueSet &Q, int g) {
                 if (!direct) return;
                 if (g == 0) {
                     Q.direct_counts = d_counts; Q.direct_fan = dfan; Q.hit_list = d_hit_list;
+                    Q.fused_lights = fuse0 ? 1u : 0u;
                     Q.hit_shard_cap = (uint32_t)(hit_cap[0] * N_SHARDS);
                     Q.out_shard_cap = (uint32_t)(ray_cap[1] * N_SHARDS);
                 } else if (g == 1) {
@@ -2377,7 +2384,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     if (gk) {
                         long long gb = (t1 - t0 + RT_GRID_BLOCK / 64 - 1) / (RT_GRID_BLOCK / 64);
                         if (gb > (long long)ctx->cu_count * grid_blocks_per_cu * rounds) gb = (long long)ctx->cu_count * grid_blocks_per_cu * rounds;
-                        hipLaunchKernelGGL((k_closest<true, true, true>), dim3((unsigned)gb), dim3(RT_GRID_BLOCK), lds_grid, st, Pg, Q);
+                        if (!Q.fused_lights) hipLaunchKernelGGL((k_closest<true, true, true>), dim3((unsigned)gb), dim3(RT_GRID_BLOCK), lds_grid, st, Pg, Q);
+                        else if (all_flat) hipLaunchKernelGGL((k_closest<true, true, true, 2>), dim3((unsigned)gb), dim3(RT_GRID_BLOCK), lds_grid, st, Pg, Q);
+                        else hipLaunchKernelGGL((k_closest<true, true, true, 1>), dim3((unsigned)gb), dim3(RT_GRID_BLOCK), lds_grid, st, Pg, Q);
                     } else
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
@@ -2453,7 +2462,9 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     if (gk) {
                         long long gb = (t1 - t0 + RT_GRID_BLOCK / 64 - 1) / (RT_GRID_BLOCK / 64);
                         if (gb > (long long)ctx->cu_count * grid_blocks_per_cu * rounds) gb = (long long)ctx->cu_count * grid_blocks_per_cu * rounds;
-                        hipLaunchKernelGGL((k_closest<true, true, true>), dim3((unsigned)gb), dim3(RT_GRID_BLOCK), lds_grid, st, Pg, Q);
+                        if (!Q.fused_lights) hipLaunchKernelGGL((k_closest<true, true, true>), dim3((unsigned)gb), dim3(RT_GRID_BLOCK), lds_grid, st, Pg, Q);
+                        else if (all_flat) hipLaunchKernelGGL((k_closest<true, true, true, 2>), dim3((unsigned)gb), dim3(RT_GRID_BLOCK), lds_grid, st, Pg, Q);
+                        else hipLaunchKernelGGL((k_closest<true, true, true, 1>), dim3((unsigned)gb), dim3(RT_GRID_BLOCK), lds_grid, st, Pg, Q);
                     } else
                     if (bvh_closest_ok) hipLaunchKernelGGL((k_closest<true, true>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
                     else hipLaunchKernelGGL((k_closest<true, false>), dim3((unsigned)blocks), dim3(block), lds_closest, st, P, Q);
@@ -2470,7 +2481,8 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                     if (timing && !(ev = next_event_pair(ctx->ev_shadow, ctx->ev_shadow_used)))
                         return fail(RT_ERR_DEVICE, "hipEventCreate failed");
                     if (ev) HIP_TRY(hipEventRecord(ev->first, sb));
-                    if (bvh_shadow_ok && grid_kernels && P.S.lg_bins)
+                    if (g == 0 && fuse0) { /* (nothing to do: generation 0 has no hit records) */ }
+                    else if (bvh_shadow_ok && grid_kernels && P.S.lg_bins)
                         hipLaunchKernelGGL(k_shadow_grid, dim3((unsigned)(ctx->cu_count * grid_blocks_per_cu * rounds)), dim3(RT_GRID_BLOCK), lds_grid, sb, Pg, Q);
                     else if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(block), lds_shadow, sb, P, Q);
                     else if (hybrid_shadow) hipLaunchKernelGGL(k_shadow_hybrid, dim3((unsigned)max_blocks), dim3(block), lds_shadow, sb, P, Q);
@@ -2664,6 +2676,7 @@ extern "C" int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value)
     else if (n == "grid") { ctx->dbg.grid = (int)value; ctx->cg_valid = false; ctx->cg_refused = false; }          // (lights' grids: read at the next upload)
     else if (n == "grid_res") ctx->dbg.grid_res = (int)value;
     else if (n == "grid_kernels") ctx->dbg.grid_kernels = (int)value;
+    else if (n == "fuse_lights") ctx->dbg.fuse_lights = (int)value;
     else if (n == "device_build_min") ctx->dbg.device_build_min = value;
     else if (n == "device_build_stack") ctx->dbg.device_build_stack = (int)value;
     else if (n == "grid_min_samples") { ctx->dbg.grid_min_samples = value; ctx->cg_refused = false; }

@@ -4,7 +4,11 @@ to be handed out in units: same primary hit ids, ray and hit counts per generati
 1e-9 of 255 (the order of the atomic sums differs).  Scenes: one ray per hit (teapot-3), two (refract, gears: the ray groups
 of a chunk are two then), spheres (balls: 128-byte hit records), transparent spheres with light cameras (glass: the shadow
 pass decides ray by ray and postpones evaluations); one batch, several batches (a small memory budget), paired passes and
-a launch per pass, parts of a frame, super-sampling."""
+a launch per pass, parts of a frame, super-sampling.
+
+With direct placement the primary pass of a scene whose shadow queries are order-free also forms the lights' terms at its
+hits itself (no hit records, no shadow pass for generation 0; option `fuse_lights`): the frames with it (teapot-3, refract and
+gears in the form for flat triangles, balls in the general form; glass does not qualify) are compared with the frames without."""
 import numpy as np
 import pytest
 
@@ -35,12 +39,14 @@ def test_direct_placement_gives_the_same_frame(scene, res, spp, pair, budget_gib
     g.upload(s)
     cam = s.camera(*res)
     frames = []
-    for direct in (0, 1):
+    for direct, fuse in ((0, 1), (1, 0), (1, 1)):
         g.set_option("direct", direct)
+        g.set_option("fuse_lights", fuse)
         frames.append(g.render(cam, num_samples=spp, flags=rt.FLAG_KEEP_ZERO_WEIGHT, seed=3))
     same_frames(frames[0], frames[1])
+    same_frames(frames[0], frames[2])
     if budget_gib:
-        assert frames[1]["stats"]["batches"] > 1
+        assert frames[2]["stats"]["batches"] > 1
     # a part of the frame (bands that do not line up with the batches)
     parts = [g.render(cam, num_samples=spp, flags=rt.FLAG_KEEP_ZERO_WEIGHT, seed=3, band_rows=24, n_parts=2, part=p) for p in (0, 1)]
     rows = [rt.part_row_indices(res[1], 24, 2, p) for p in (0, 1)]
