@@ -289,12 +289,17 @@ def main():
     # per-kernel times: a few extra frames with HIP events around every launch on the render stream
     prof_steps = max(1, min(steps, 5))
     kt = {"closest_ms": 0.0, "shadow_ms": 0.0, "primary_ms": 0.0, "closest_launches": 0, "shadow_launches": 0,
-          "primary_launches": 0, "closest_rays": 0, "shadow_rays": 0, "gpu_ms": 0.0, "primary_rays": 0}
+          "primary_launches": 0, "closest_rays": 0, "shadow_rays": 0, "gpu_ms": 0.0, "primary_rays": 0, "primary_hits": 0}
     for _ in range(prof_steps):
         st = step(args.flags | rt.FLAG_TIMING)
         for k in kt:
-            kt[k] += st["rays_per_generation"][0] if k == "primary_rays" else st[k]
+            kt[k] += st["rays_per_generation"][0] if k == "primary_rays" else (st["hits_per_generation"][0] if k == "primary_hits" else st[k])
     fence()
+    # A primary pass that deals with the lights at its hits itself (no shadow pass for generation 0: one shadow launch fewer
+    # than closest-hit launches per batch) traces those shadow rays too: they count with the pass that traces them.
+    n_lights = len(scene.lights())
+    fused_lights = 0 < kt["shadow_launches"] < kt["closest_launches"]
+    own_shadow_rays = kt["primary_hits"] * n_lights if fused_lights else 0
 
     if world > 1:
         t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=dev)
@@ -321,11 +326,11 @@ def main():
             classes = {"k_local / k_fused (the frame is one launch)": ("fused", kt["primary_ms"], kt["primary_launches"], kt["closest_rays"] + kt["shadow_rays"])}
         else:
             classes = {
-                "primary pass: k_closest<true, true, *>": ("primary", kt["primary_ms"], kt["primary_launches"], kt["primary_rays"]),
+                "primary pass: k_closest<true, true, *>": ("primary", kt["primary_ms"], kt["primary_launches"], kt["primary_rays"] + own_shadow_rays),
                 "queued closest-hit passes: k_closest<false, true, *>": ("queued", kt["closest_ms"] - kt["primary_ms"],
                                                                          kt["closest_launches"] - kt["primary_launches"],
                                                                          kt["closest_rays"] - kt["primary_rays"]),
-                "shadow passes: k_shadow<true> / k_shadow_grid": ("shadow", kt["shadow_ms"], kt["shadow_launches"], kt["shadow_rays"]),
+                "shadow passes: k_shadow<true> / k_shadow_grid": ("shadow", kt["shadow_ms"], kt["shadow_launches"], kt["shadow_rays"] - own_shadow_rays),
             }
         kname = max(classes, key=lambda k: classes[k][1])
         dom, ms_total, launches, rays_k = classes[kname]
@@ -341,6 +346,7 @@ def main():
                     "rays_per_launch": rays_k / launches, "build_id": build_id,
                     "kernel_ms_per_frame": {k: v[1] / prof_steps for k, v in classes.items()},
                     "frame_gpu_ms": kt["gpu_ms"] / prof_steps,
+                    "primary_pass_shades_its_hits": bool(fused_lights),
                     "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None}
         if stale:
             roofline["counters"] = stale
@@ -365,7 +371,7 @@ def main():
             # what this build's own traversal needs per ray: node steps and leaf tests counted by the -DRT_COUNT build,
             # plus the queue records the kernel reads and writes
             w = walk[dom]
-            queue_b = {"primary": 64 + 80, "queued": 80 + 64 + 80, "shadow": 64 / max(walk.get("lights", 1), 1) + 24,
+            queue_b = {"primary": 80 if fused_lights else 64 + 80, "queued": 80 + 64 + 80, "shadow": 64 / max(walk.get("lights", 1), 1) + 24,
                        "fused": 24}[dom]
             alg = w["nodes_per_ray"] * BVH_NODE_B + w["tri_tests_per_ray"] * LEAF_TRI_B + w["sph_tests_per_ray"] * LEAF_SPH_B + queue_b
             roofline["algorithmic"] = {"bytes_per_ray": alg, "bytes_per_launch": alg * rays_k / launches,

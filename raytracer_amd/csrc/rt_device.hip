@@ -2477,11 +2477,12 @@ static int enqueue_frame(rt_ctx *ctx, const rt_camera *cam, const rt_render_opts
                 HIP_TRY(hipEventRecord(ctx->ev_c[g], st));
                 if (P.S.n_lights > 0) {
                     HIP_TRY(hipStreamWaitEvent(sb, ctx->ev_c[g], 0));
+                    const bool no_hits = g == 0 && fuse0;      // (generation 0 has no hit records: nothing to launch, nothing to time)
                     ev = nullptr;
-                    if (timing && !(ev = next_event_pair(ctx->ev_shadow, ctx->ev_shadow_used)))
+                    if (timing && !no_hits && !(ev = next_event_pair(ctx->ev_shadow, ctx->ev_shadow_used)))
                         return fail(RT_ERR_DEVICE, "hipEventCreate failed");
                     if (ev) HIP_TRY(hipEventRecord(ev->first, sb));
-                    if (g == 0 && fuse0) { /* (nothing to do: generation 0 has no hit records) */ }
+                    if (no_hits) { }
                     else if (bvh_shadow_ok && grid_kernels && P.S.lg_bins)
                         hipLaunchKernelGGL(k_shadow_grid, dim3((unsigned)(ctx->cu_count * grid_blocks_per_cu * rounds)), dim3(RT_GRID_BLOCK), lds_grid, sb, Pg, Q);
                     else if (bvh_shadow_ok) hipLaunchKernelGGL((k_shadow<true>), dim3((unsigned)max_blocks), dim3(block), lds_shadow, sb, P, Q);
