@@ -216,10 +216,16 @@ int rt_noalloc_scratch_bytes(size_t *bytes);
  * size: paired passes, passes on two streams, the lane-per-sample kernel, the self-contained blocks), "local_threads"
  * (256, 512, 1024), "local_rotate" (places a block's share of the primary chunks moves on per round, -1 = by image
  * width), "local_min_chunks" (primary chunks a self-contained block gets at least, 0 = four), "whole_chunks" (how many
- * generations of closest-hit passes push whole chunks of records, 0..6, -1 = default), "units" (0: the primary pass keeps fixed shares per block), "lightcam_host" (1: light-camera trees
+ * generations of closest-hit passes push whole chunks of records, 0..6, -1 = default), "units" (0: the primary pass keeps fixed shares per block),
+ * "direct" (0: the primary pass takes its places in the queues from counters instead of from the chunk's number),
+ * "fuse_lights" (0: the primary pass leaves the lights at its hits to a shadow pass of its own), "grid", "grid_res",
+ * "grid_min_samples", "grid_kernels" (the view grids: which are made, how fine, from which frame size, and whether the
+ * kernels that only read them are used), "stack_min", "ring_poison", "lightcam_levels", "lightcam_digits",
+ * "lightcam_host" (1: light-camera trees
  * built on the host), "lightcam_pool" (128..1536: places used of the pool of pending cells that a wave's 64 density
  * queries share; a full pool slows the pass down, it loses nothing); and for the next rt_upload_scene "leaf_max"
- * (1..4), "split_budget" (percent). */
+ * (1..4), "split_budget" (percent), "device_build_min" and "device_build_stack" (primitives from which a hierarchy is
+ * built on the device, and the stack need beyond which that result is discarded for the host builder's). */
 int rt_debug_set_option(rt_ctx *ctx, const char *name, int64_t value);
 
 /* ---- several GPUs of one node ----

@@ -196,7 +196,7 @@ struct QueueSet {
     // passes that read what it wrote):
     uint32_t *direct_counts;         // PRIMARY, or null: chunk c of the batch writes its hits to records c * 64 ... of `hits` and its
                                      //   rays to records c * 64 * direct_fan ... of `rays_out` (fillers up to whole groups of 64 as with
-                                     //   whole_chunks), and leaves hits | rays << 8 in direct_counts[c]
+                                     //   whole_chunks), and leaves hits | rays << 8 (| hits shaded in place << 16, see fused_lights) in direct_counts[c]
     uint32_t direct_fan;             //   groups of 64 ray records a primary chunk can fill (1, or 2 where a hit can spawn two rays)
     uint32_t fused_lights;           // PRIMARY with direct_counts, grid-only kernel: the lights' terms of a primary hit are formed in the primary
                                      //   pass itself (shade_primary_hit) and no hit record is written; such hits are counted in bits 16..23

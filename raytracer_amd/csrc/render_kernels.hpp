@@ -2,6 +2,12 @@
 //   k_closest<PRIMARY>  ray generation (Camera.h:112-230) fused with the closest-hit query, the hit
 //                       record (Solid.h:110-125) and secondary-ray spawning (Camera.h:232-314)
 //   k_closest<queued>   the same for generations 1..5, rays read from the queue
+//   k_closest<.., GRID, FUSE>  the primary pass of a frame whose eye has a view grid (no walk compiled in); FUSE: it also forms
+//                       the lights' terms at its hits (shade_primary_hit), so generation 0 has no hit records and no shadow pass
+//   k_compact_direct    lists the groups of records a primary pass with direct placement filled
+//   k_shadow_grid       the shadow pass of a scene whose lights have view grids and whose queries are order-free
+//   k_pair, k_local, k_fused   a shadow pass and the next closest-hit pass in one launch; a whole frame in one launch of
+//                       self-contained blocks; a lane per sample for scenes without secondary rays
 //   k_shadow, k_shadow_hybrid   one item per (hit, light): shadow query (Octree.h:1198-1264), Phong terms
 //                       (Camera.h:365-488), FP64 accumulation into the frame
 //   k_lightcam          deferred light-camera density queries (Camera.h:406-451)
@@ -109,8 +115,6 @@ DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, i
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
-// One 64-ray chunk of a closest-hit pass: the rays (generated, or read from the queue), the closest-hit query, the hit
-// record and the pushes of the hit and of the secondary rays.
 // The lights' terms at a primary hit, formed where the hit was found (the grid-only primary kernel of a scene whose shadow
 // queries are order-free and whose lights have grids, FUSE): what shadow_chunk does for a hit record, without the record --
 // the hit is neither written nor read back.  Returns the sum of the terms of the lights that reach the hit (`*lit_any`:
@@ -152,6 +156,8 @@ DEV d3 shade_primary_hit(const FrameParams &P, bool active, d3 Pt, d3 vv, d3 n2,
     return sum;
 }
 
+// One 64-ray chunk of a closest-hit pass: the rays (generated, or read from the queue), the closest-hit query, the hit
+// record and the pushes of the hit and of the secondary rays.
 // FUSE (grid-only primary kernel): 1 the lights' terms of a hit are formed here, 2 the same for a scene whose hits are all
 // flat triangles' (no normals held through the queries).
 template <bool PRIMARY, bool BVH, bool GRID = false, int FUSE = 0>

@@ -1494,7 +1494,10 @@ static int build_light_grids(rt_ctx *ctx, DevScene &D, int n_sph_records)
     D.lg_bins = nullptr; D.lg_entries = nullptr; D.lg_res = 0;
     const int mode = ctx->dbg.grid;
     if (!(mode == 1 || mode == 2) || !ctx->accel_usable || D.n_lights < 1 || D.n_lights > 16) return RT_OK;
-    int res = ctx->dbg.grid_res > 0 ? ctx->dbg.grid_res : 256;
+    // 256 bins to a face's edge; 512 for a scene of few primitives, whose lists then take a millisecond more to make and are a
+    // fifth shorter (8K teapot frame 36.7 -> 35.5 ms, balls at 4096 x 4096 5.74 -> 5.31; small frames the same) -- for the 72 k
+    // triangles of gears the finer grids would take 51 ms instead of 19
+    int res = ctx->dbg.grid_res > 0 ? ctx->dbg.grid_res : ((long long)ctx->n_grid_tri + n_sph_records <= 8192 ? 512 : 256);
     if (res < 8) res = 8;
     if (res > 1024) res = 1024;
     const auto t_begin = std::chrono::steady_clock::now();
