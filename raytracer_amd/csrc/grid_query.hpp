@@ -87,10 +87,15 @@ DEV bool grid_any(const DevScene &S, const vg::Bin *bins, uint32_t bin, const vg
 // Nearest hit over the bin's list, ties by the records' keys (the reference's visiting order).  The parameter of a
 // hit is its distance from the eye (unit direction): an entry whose lower bound lies beyond the nearest hit so far ends
 // the loop (a tie is not beyond).
+// (`l`: the bin's list with its head fetched, grid_list())
+DEV void grid_closest_in(const DevScene &S, GridList l, d3 o, d3 d, double d2, Best &best, WalkCount &wc);
 DEV void grid_closest(const DevScene &S, const vg::Bin *bins, uint32_t bin, const vg::Entry *entries, d3 o, d3 d, double d2, Best &best, WalkCount &wc)
 {
+    grid_closest_in(S, grid_list(bins, bin, entries), o, d, d2, best, wc);
+}
+DEV void grid_closest_in(const DevScene &S, GridList l, d3 o, d3 d, double d2, Best &best, WalkCount &wc)
+{
     const double minT = .01, maxT = 10000000000.0;
-    GridList l = grid_list(bins, bin, entries);
     for (uint32_t k = 0; k < l.count; ++k) {
         const grid_v2u e = l.cur;
         if (best.t < maxT && __uint_as_float(e.y) > (float)best.t * (1.0f + 0x1p-16f) + 1e-6f) break;

@@ -156,6 +156,28 @@ DEV void accum_add_runs(double *accum, bool in_queue, bool valid, uint32_t pixel
     }
 }
 
+// The same when every lane of the queue adds the same amount w*c (the background to the samples of a chunk that hit
+// nothing): a run's sum is its length times that amount, no partial sums travel between lanes.
+DEV void accum_add_equal(double *accum, bool in_queue, uint32_t pixel, double w, d3 c)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t key = in_queue ? pixel : 0xFFFFFFFFu;
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    const bool head = (lane == 0) || prev != key;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long above = heads & ~((2ull << lane) - 1ull);
+    const int run_last = above ? __ffsll((unsigned long long)above) - 2 : 63;
+    if (in_queue && head) {
+        const double n = (double)(run_last - lane + 1);
+        const double vx = n * (w * c.x), vy = n * (w * c.y), vz = n * (w * c.z);
+        if (vx != 0.0 || vy != 0.0 || vz != 0.0) {
+            unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 0], vx);
+            unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 1], vy);
+            unsafeAtomicAdd(&accum[(size_t)pixel * 3 + 2], vz);
+        }
+    }
+}
+
 // Queue records move as whole 16-byte pieces, all pieces of a record issued together: the compiler,
 // left to the individual fields, splits a record into a dozen narrower accesses placed where each
 // field happens to be used, and the memory pipeline charges per instruction, not per byte

@@ -40,8 +40,14 @@ DEV void camera_to_lds(const FrameParams &P)
 // pixel in consecutive positions; a wave takes 64 consecutive positions.
 // Positions are counted from the batch's first block, which keeps them in 32 bits, and every
 // division is by a number fixed for the launch (a multiplication, see FastDiv).
-DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, int lane, bool *active_out, d3 *o_out, d3 *d_out,
-                     uint32_t *pixel_out, bool *first_out, uint32_t *tile_out)
+// (in two halves: where the sample lies -- pixel, tile, sub-sample -- and, from that, its ray; a chunk whose tiles hold nothing
+// needs only the first)
+struct PrimarySample {
+    bool active, first;
+    uint32_t pixel, tile;
+    int i, j, si, sj;
+};
+DEV PrimarySample primary_sample(const FrameParams &P, const QueueSet &Q, long long chunk, int lane)
 {
     const int N = P.N;
     const uint32_t rel = (uint32_t)chunk * 64u + (uint32_t)lane;
@@ -57,11 +63,19 @@ DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, i
     const long long lrow_ll = by * 8 + (within >> 3);
     const int lrow = lrow_ll < P.local_rows ? (int)lrow_ll : P.local_rows;     // beyond the part: inactive below
     const int si = (int)fast_div((uint32_t)smp, P.div_n), sj = smp - si * N;
-    *active_out = j < P.cam.resx && lrow < P.local_rows;
+    PrimarySample ps;
+    ps.active = j < P.cam.resx && lrow < P.local_rows;
     const int i = global_row(P, lrow);
-    *pixel_out = (uint32_t)lrow * (uint32_t)P.cam.resx + (uint32_t)j;
-    *tile_out = ((uint32_t)i >> 3) * (uint32_t)P.cg_tiles_x + ((uint32_t)j >> 3);      // the sample's 8 x 8-pixel tile of the whole frame
-    *first_out = (si == 0 && sj == 0);
+    ps.pixel = (uint32_t)lrow * (uint32_t)P.cam.resx + (uint32_t)j;
+    ps.tile = ((uint32_t)i >> 3) * (uint32_t)P.cg_tiles_x + ((uint32_t)j >> 3);      // the sample's 8 x 8-pixel tile of the whole frame
+    ps.first = (si == 0 && sj == 0);
+    ps.i = i; ps.j = j; ps.si = si; ps.sj = sj;
+    return ps;
+}
+DEV void primary_ray_of(const FrameParams &P, const PrimarySample &ps, d3 *o_out, d3 *d_out)
+{
+    const int N = P.N;
+    const int i = ps.i, j = ps.j, si = ps.si, sj = ps.sj;
     struct { double d, l, t, pix_width; int resx; } c;
     d3 u, v, w, e;
     {
@@ -110,6 +124,13 @@ DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, i
     }
     *o_out = o;
     *d_out = d;
+}
+DEV void primary_ray(const FrameParams &P, const QueueSet &Q, long long chunk, int lane, bool *active_out, d3 *o_out, d3 *d_out,
+                     uint32_t *pixel_out, bool *first_out, uint32_t *tile_out)
+{
+    const PrimarySample ps = primary_sample(P, Q, chunk, lane);
+    *active_out = ps.active; *pixel_out = ps.pixel; *first_out = ps.first; *tile_out = ps.tile;
+    primary_ray_of(P, ps, o_out, d_out);
 }
 
 #ifndef RT_MIN_WAVES
@@ -171,7 +192,18 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     double A = 1.0, coef = 1.0;
     uint32_t pixel = 0, meta = 5u | 0x100u, tile = 0;
     bool first_sample = false;
-    if (PRIMARY) {
+    GridList tile_list{};
+    bool traced = true;
+    if (PRIMARY && GRID) {
+        // Where the samples lie first, and their tiles' lists: a chunk none of whose samples has anything in its tile (sky)
+        // hits nothing whatever its rays are, and they are not formed.
+        const PrimarySample ps = primary_sample(P, Q, chunk, lane);
+        active = ps.active; pixel = ps.pixel; first_sample = ps.first; tile = ps.tile;
+        tile_list = grid_list(P.cg_bins, tile, P.cg_entries);
+        traced = __ballot(active && tile_list.count != 0u) != 0ull;
+        o = d = mk3(0, 0, 0);
+        if (traced) primary_ray_of(P, ps, &o, &d);
+    } else if (PRIMARY) {
         primary_ray(P, Q, chunk, lane, &active, &o, &d, &pixel, &first_sample, &tile);
     } else {
         int shard;
@@ -194,14 +226,16 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     double best_t = 0;
     int best = -1, best_prim = -1;
     STAMP(3);
-    if (active) {
+    if (active && traced) {
         if (BVH) {
             const double d2 = dot3(d, d);
             Best bst;
             bst.t = 10000000000.0; bst.key = 0x7fffffff; bst.slot = -1; bst.prim = -1;
             if (root_gate(P.S, o, d, d2, 10000000000.0)) {
                 WC_ADD(wc, rays);
-                if (GRID || (PRIMARY && P.cg_bins)) {
+                if (PRIMARY && GRID) {
+                    grid_closest_in(P.S, tile_list, o, d, d2, bst, wc);
+                } else if (GRID || (PRIMARY && P.cg_bins)) {
                     // every primary ray of a pinhole frame starts at the eye: the list of the sample's 8 x 8-pixel tile holds
                     // all it can meet (grid_query.hpp)
                     grid_closest(P.S, P.cg_bins, tile, P.cg_entries, o, d, d2, bst, wc);
@@ -217,6 +251,8 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
         } else {
             trace_closest(P.S, o, d, cull, .01, best_t, best);
         }
+    } else if (active) {
+        WC_ADD(wc, rays);       // (a sample whose tile is empty: counted as the ray it stands for)
     }
     const rt_tri_rec *tri_arr = BVH ? P.S.btri : P.S.tri;
     const rt_sph_rec *sph_arr = BVH ? P.S.bsph : P.S.sph;
@@ -227,6 +263,17 @@ DEV void closest_chunk(const FrameParams &P, const QueueSet &Q, const ShardMap &
     const int L = (int)(meta & 0xffu);
     const double wloc = first ? A : A * coef;
     bool hit = active && best >= 0;
+    if (PRIMARY && GRID) {
+        if (__ballot(hit) == 0ull) {
+            // nothing was hit: the samples add the background and the chunk leaves no records
+            if (active && first_sample && P.hit_id) P.hit_id[pixel] = -1;
+            accum_add_equal(P.accum, active, pixel, wloc, ld3(P.S.bg));       // (a primary sample's weight is 1: the same amount in every lane)
+            if (Q.direct_counts != nullptr) {
+                if (lane == 0) Q.direct_counts[(uint32_t)chunk] = 0u;
+            }
+            return;
+        }
+    }
 
     // hit record (Solid.h:110-125)
     d3 n = mk3(0, 0, 0), Pt = mk3(0, 0, 0);
