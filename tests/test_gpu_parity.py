@@ -5,7 +5,8 @@ Bars (per the north-star of this build):
     in the same order, so even exact-t ties resolve the same way);
   * image: >= 99.9 % of pixels within 1/255 per channel -- asserted here in the much stronger
     form "8-bit image identical, f64 frame within 1e-9 of 255", because both sides evaluate the
-    same IEEE FP64 operations; only pow() and the summation order of a pixel's contributions differ;
+    same IEEE FP64 operations; only the specular power (within 1.3e-14 of pow(), tests/test_gpu_specular_power.py) and
+    the summation order of a pixel's contributions differ;
   * ray counts: equal to the oracle's (with zero-weight reflection rays kept, as the reference does).
 """
 import numpy as np
